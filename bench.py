@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- M particle-steps/s of the WCSPH dam-break step on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line
+from rank 0.  A "step" is one full WCSPH step (neighbour-table build, density pass, fused
+pressure+viscosity force + integrate) of the synthetic dam-break with the particle state
+already resident in HBM.  N=1 workload: BASELINE.json configs[3]'s 16M-particle block
+(n3=252 -> 16,003,008 particles) on one GPU; N>1: the same total problem partitioned into
+spatial slabs (strong scaling), see dieselfluid_amd/slab.py.
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel: algorithmic bytes per launch / HIP-event duration
+  cpu_baseline -- the CPU oracle (a port of the reference's single-threaded Go path)
+                  timed on a bounded sample of the same workload, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic bytes per particle per launch (DESIGN.md "Kernels"):
+#   density: read x (12) write rho (4)                       [SURVEY 8d: 16 B]
+#   force+integrate: read x,v,rho (28), write x,v (24)        [SURVEY 8d: 52 B]
+BYTES_DENSITY = 16
+BYTES_FORCE = 52
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n3", type=int, default=252, help="fluid block edge in particles (252 -> 16.0M)")
+    ap.add_argument("--math", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle (single-threaded C port of the reference loops) on a bounded sample: the same
+    dam-break scene and parameters at a smaller block, a few steps."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    from dieselfluid_amd import scenes
+    from oracle import pyoracle as po
+
+    n3 = args.cpu_n3
+    p, pos = scenes.dambreak_scene(n3)
+    frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (n3 ** 3, 1))
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, force=frc)
+    t0 = time.perf_counter()
+    ora.wcsph_step(args.cpu_steps)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n3 ** 3 * args.cpu_steps / dt / 1e6, 4),
+        "unit": "M particle-steps/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"same dam-break scene at n3={n3} ({n3**3} particles), {args.cpu_steps} WCSPH steps, "
+                  f"{dt:.1f} s of CPU; oracle/dsl_oracle.c single thread",
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from dieselfluid_amd import SPHEngine, scenes
+
+    math_mode = 1 if args.math == "fast" else 0
+    n3 = args.n3
+    n_total = n3 ** 3
+
+    if world == 1:
+        p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+        eng = SPHEngine(p, device=local_rank)
+        eng.upload("positions", pos)
+        eng.upload("forces", np.tile(np.array(p.force_reset[:], dtype=np.float32), (n_total, 1)))
+        del pos
+        step = eng.wcsph_step
+        engines = [eng]
+    else:
+        from dieselfluid_amd import slab
+        drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank)
+        step = drv.wcsph_step
+        engines = [drv.engine]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step(args.warmup)
+    for e in engines:
+        e.timing_reset()
+        e.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    step(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    for e in engines:
+        e.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    eng = engines[0]
+    ms_d, n_d = eng.timing("density")
+    ms_f, n_f = eng.timing("force_integrate")
+    n_local = eng.n
+    if ms_f >= ms_d:
+        kname, kms, kbytes = "k_force_integrate", ms_f, BYTES_FORCE
+    else:
+        kname, kms, kbytes = "k_density", ms_d, BYTES_DENSITY
+    achieved = n_local * kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    st = eng.stats()
+
+    if rank == 0:
+        value = n_total * args.steps / dt / 1e6
+        out = {
+            "metric": "M particle-steps/sec, 16M-particle WCSPH dam-break; % HBM roofline",
+            "value": round(value, 3),
+            "unit": "M particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"WCSPH dam-break, {n_total} particles (n3={n3}), h=2dx, uniform-grid neighbours, "
+                            f"density + pressure/viscosity force + integrate + walls, math={args.math}",
+                "particles": n_total,
+                "parallelism": "single GPU" if world == 1 else f"{world} spatial slabs + 2h halo",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": kname,
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "avg_ms": round(kms, 4),
+                "bytes_per_particle": kbytes,
+                "pass_density_ms": round(ms_d, 4),
+                "pass_force_ms": round(ms_f, 4),
+                "pass_frac_68B": round(n_local * 68 / ((ms_d + ms_f) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                if (ms_d + ms_f) > 0 else None,
+            },
+            "kernels_ms": {k: round(eng.timing(k)[0], 4) for k in ("cell_rank", "scan", "scatter", "density",
+                                                                     "force_integrate")},
+            "max_vel": st.max_vel,
+            "max_cell_count": st.max_cell_count,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,902 @@
+// dslsph.hip -- C ABI (include/dslsph.h) of the gfx950 SPH particle-step engine.
+//
+// Device data layout (all float32, SoA, resident in HBM for the life of the handle):
+//   pos/vel        2 x 6 arrays  ping-pong: the counting sort scatters cur -> other, the
+//                                fused force+integrate kernel writes other (Jacobi)
+//   ids            2 x 1 int     slot -> original particle index (host order)
+//   forces         2 x 3 arrays  only materialised while they differ from force_reset
+//   pci pos/vel    2 x 6 arrays  PCISPH predictor state (pcisph_darwin.go:28-41)
+//   rho, pterm, press            per-slot density, P/rho^2, "pressures" buffer
+//   cellid, rank, cell_count, cell_start, block_sums   neighbour table
+// Host buffers are the reference's interleaved xyz float32 (model/particle_array.go:5-15).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see
+// __graft_entry__.build()).  gfx950 only; no CPU fallback exists in this library.
+#include "../../include/dslsph.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "kernels_sph.hpp"
+
+using namespace dsl;
+
+namespace {
+std::string g_create_error;
+}
+
+struct dsl_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  dsl_params prm{};
+  DevConsts c{};
+  int n = 0, ncell = 0, ncell_pad = 0, nscan = 0;
+  // SoA state
+  float* pv[2][6] = {};
+  int* ids[2] = {};
+  float* frc[2][3] = {};
+  float* pci[2][6] = {};
+  float *rho = nullptr, *pterm = nullptr, *press = nullptr, *scratch1 = nullptr;
+  int *cellid = nullptr, *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
+  float* stage = nullptr;
+  DevStats* dstats = nullptr;
+  int cur_pv = 0, cur_ids = 0, cur_f = 0, cur_pci = 0;
+  bool grid_valid = false, forces_uniform = false, press_zero = true, pci_active = false, dens_fresh = false;
+  int64_t steps = 0;
+  std::string err;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[DSL_K_COUNT];
+  double total_ms[DSL_K_COUNT] = {};
+  int64_t launches[DSL_K_COUNT] = {};
+};
+
+namespace {
+
+int fail(dsl_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                             \
+  do {                                                                                               \
+    hipError_t e__ = (expr);                                                                         \
+    if (e__ != hipSuccess)                                                                           \
+      return fail((h), DSL_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+  } while (0)
+
+#define CHECK_HANDLE(h)                                   \
+  do {                                                    \
+    if (!(h)) return fail(nullptr, DSL_ERR_INVALID, "null handle"); \
+    hipError_t e__ = hipSetDevice((h)->device);           \
+    if (e__ != hipSuccess) return fail((h), DSL_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e__)); \
+  } while (0)
+
+inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+// Fills the device constants from the parameter block; host arithmetic mirrors
+// kernel.Build_Kernel (kernel/std_kernel.go:20-31) in float32.
+int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
+  if (!(p.h > 0.0f)) return fail(h, DSL_ERR_INVALID, "h must be > 0");
+  if (!(p.mass > 0.0f)) return fail(h, DSL_ERR_INVALID, "mass must be > 0");
+  if (p.n_particles <= 0) return fail(h, DSL_ERR_INVALID, "n_particles must be > 0");
+  if (p.n_boundary != 0)
+    return fail(h, DSL_ERR_UNSUPPORTED, "boundary particles are not supported (disabled in the reference, fluid.go:70)");
+  if (p.neigh_mode != DSL_NEIGH_GRID) return fail(h, DSL_ERR_UNSUPPORTED, "neigh_mode must be DSL_NEIGH_GRID");
+  if (p.math_mode != DSL_MATH_EXACT && p.math_mode != DSL_MATH_FAST) return fail(h, DSL_ERR_INVALID, "bad math_mode");
+  c.n = p.n_particles;
+  const float hh = p.h;
+  c.h = hh;
+  c.hh = hh * hh;
+  c.inv_h = 1.0f / hh;
+  c.inv_hh = 1.0f / c.hh;
+  const float H3 = hh * hh * hh, H4 = hh * hh * hh * hh, H5 = hh * hh * hh * hh * hh;
+  const double PI = 3.141592653589;  // kernel/std_kernel.go:5
+  c.A = 315.0f / ((float)(64.0 * PI) * H3);
+  c.B = -45.0f / ((float)PI * H4);
+  c.C = 90.0f / ((float)PI * H5);
+  c.W0 = (c.A * 1.0f) * 1.0f;  // F(0): q = 1 - 0/hh = 1
+  c.mass = p.mass;
+  c.inv_mass = 1.0f / p.mass;
+  c.ref_density = p.ref_density;
+  c.mu = p.mu;
+  c.dt = p.dt;
+  c.delta = p.delta;
+  c.eos_wg = p.eos_w / p.eos_gamma;
+  c.eos_gamma = p.eos_gamma;
+  c.eos_d0_grad = p.eos_d0_grad;
+  c.pressure_sign = p.pressure_sign;
+  c.visc_running_mass = p.visc_running_mass;
+  for (int a = 0; a < 3; ++a) {
+    c.reset[a] = p.force_reset[a];
+    c.ext[a] = p.external[a];
+    c.bmin[a] = p.box_min[a];
+    c.bmax[a] = p.box_max[a];
+    c.gmin[a] = p.grid_min[a];
+  }
+  c.wcsph_pressure_force = p.wcsph_pressure_force;
+  c.wcsph_viscosity = p.wcsph_viscosity;
+  c.pci_max_error = p.pci_max_error;
+  c.walls = p.walls;
+  c.rest = p.restitution;
+  c.inv_cell = 1.0f / hh;
+  long long ncell = 1;
+  for (int a = 0; a < 3; ++a) {
+    int d = (int)ceilf((p.grid_max[a] - p.grid_min[a]) * c.inv_cell);
+    if (!(p.grid_max[a] > p.grid_min[a])) return fail(h, DSL_ERR_INVALID, "grid_max must exceed grid_min");
+    if (d < 1) d = 1;
+    c.dims[a] = d;
+    ncell *= d;
+  }
+  if (ncell > (1ll << 30)) return fail(h, DSL_ERR_INVALID, "grid has more than 2^30 cells; shrink the grid box or enlarge h");
+  c.ncell = (int)ncell;
+  return DSL_OK;
+}
+
+template <class T>
+int dev_alloc(dsl_handle* h, T** p, size_t count) {
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return fail(h, DSL_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return DSL_OK;
+}
+
+hipEvent_t get_event(dsl_handle* h) {
+  if (!h->pool.empty()) {
+    hipEvent_t e = h->pool.back();
+    h->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+template <class F>
+int timed(dsl_handle* h, int kid, F&& launch) {
+  if (h->timing) {
+    hipEvent_t a = get_event(h), b = get_event(h);
+    (void)hipEventRecord(a, h->stream);
+    launch();
+    (void)hipEventRecord(b, h->stream);
+    h->pending[kid].emplace_back(a, b);
+  } else {
+    launch();
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, DSL_ERR_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+  return DSL_OK;
+}
+
+int drain_timing(dsl_handle* h) {
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int k = 0; k < DSL_K_COUNT; ++k) {
+    for (auto& pr : h->pending[k]) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        h->total_ms[k] += ms;
+        h->launches[k] += 1;
+      }
+      h->pool.push_back(pr.first);
+      h->pool.push_back(pr.second);
+    }
+    h->pending[k].clear();
+  }
+  return DSL_OK;
+}
+
+CSoa3 cpos(dsl_handle* h) { return {h->pv[h->cur_pv][0], h->pv[h->cur_pv][1], h->pv[h->cur_pv][2]}; }
+CSoa3 cvel(dsl_handle* h) { return {h->pv[h->cur_pv][3], h->pv[h->cur_pv][4], h->pv[h->cur_pv][5]}; }
+Soa3 mpos(dsl_handle* h, int w) { return {h->pv[w][0], h->pv[w][1], h->pv[w][2]}; }
+Soa3 mvel(dsl_handle* h, int w) { return {h->pv[w][3], h->pv[w][4], h->pv[w][5]}; }
+Soa3 mfrc(dsl_handle* h) { return {h->frc[h->cur_f][0], h->frc[h->cur_f][1], h->frc[h->cur_f][2]}; }
+CSoa3 cfrc(dsl_handle* h) { return {h->frc[h->cur_f][0], h->frc[h->cur_f][1], h->frc[h->cur_f][2]}; }
+Soa3 mpcip(dsl_handle* h) { return {h->pci[h->cur_pci][0], h->pci[h->cur_pci][1], h->pci[h->cur_pci][2]}; }
+Soa3 mpciv(dsl_handle* h) { return {h->pci[h->cur_pci][3], h->pci[h->cur_pci][4], h->pci[h->cur_pci][5]}; }
+
+// forces are kept implicit (== force_reset) after Update until a pass needs the array
+int materialise_forces(dsl_handle* h) {
+  if (!h->forces_uniform) return DSL_OK;
+  Soa3 f = mfrc(h);
+  const DevConsts& c = h->c;
+  hipLaunchKernelGGL(k_fill3, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->n, f.x, f.y, f.z, c.reset[0],
+                     c.reset[1], c.reset[2]);
+  HIP_TRY(h, hipGetLastError());
+  h->forces_uniform = false;
+  return DSL_OK;
+}
+int materialise_press(dsl_handle* h) {
+  if (!h->press_zero) return DSL_OK;
+  HIP_TRY(h, hipMemsetAsync(h->press, 0, sizeof(float) * (size_t)h->n, h->stream));
+  h->press_zero = false;
+  return DSL_OK;
+}
+
+// cell hash -> histogram -> prefix sum -> counting-sort scatter.  carry_derived also
+// permutes rho/pterm/press so that an explicit dsl_build_neighbours keeps them usable.
+int build_grid(dsl_handle* h, bool carry_derived) {
+  const int n = h->n;
+  const DevConsts& c = h->c;
+  CSoa3 p = cpos(h);
+  HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+  HIP_TRY(h, hipMemsetAsync(&h->dstats->max_cell_count, 0, sizeof(int), h->stream));
+  int rc = timed(h, DSL_K_CELL_RANK, [&] {
+    hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z, h->cellid,
+                       h->rank, h->cell_count);
+  });
+  if (rc) return rc;
+  rc = timed(h, DSL_K_SCAN, [&] {
+    hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan);
+    hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
+                       h->cell_start, h->dstats);
+  });
+  if (rc) return rc;
+  ScatterArrays a{};
+  int nf = 0;
+  const int s = h->cur_pv, d = s ^ 1;
+  for (int k = 0; k < 6; ++k) {
+    a.src[nf] = h->pv[s][k];
+    a.dst[nf++] = h->pv[d][k];
+  }
+  if (!h->forces_uniform)
+    for (int k = 0; k < 3; ++k) {
+      a.src[nf] = h->frc[h->cur_f][k];
+      a.dst[nf++] = h->frc[h->cur_f ^ 1][k];
+    }
+  if (h->pci_active)
+    for (int k = 0; k < 6; ++k) {
+      a.src[nf] = h->pci[h->cur_pci][k];
+      a.dst[nf++] = h->pci[h->cur_pci ^ 1][k];
+    }
+  // derived arrays travel through the scratch buffer one at a time (rare path)
+  a.nf = nf;
+  a.ids_src = h->ids[h->cur_ids];
+  a.ids_dst = h->ids[h->cur_ids ^ 1];
+  rc = timed(h, DSL_K_SCATTER, [&] {
+    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, a, h->cellid, h->rank,
+                       h->cell_start);
+  });
+  if (rc) return rc;
+  if (carry_derived) {
+    float* derived[3] = {h->dens_fresh ? h->rho : nullptr, h->dens_fresh ? h->pterm : nullptr,
+                         h->press_zero ? nullptr : h->press};
+    for (float* arr : derived) {
+      if (!arr) continue;
+      ScatterArrays b{};
+      b.src[0] = arr;
+      b.dst[0] = h->scratch1;
+      b.nf = 1;
+      b.ids_src = h->ids[h->cur_ids];      // ids re-scattered identically; harmless
+      b.ids_dst = h->ids[h->cur_ids ^ 1];
+      hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, b, h->cellid, h->rank,
+                         h->cell_start);
+      HIP_TRY(h, hipGetLastError());
+      HIP_TRY(h, hipMemcpyAsync(arr, h->scratch1, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    }
+  } else {
+    h->dens_fresh = false;
+  }
+  h->cur_pv ^= 1;
+  h->cur_ids ^= 1;
+  if (!h->forces_uniform) h->cur_f ^= 1;
+  if (h->pci_active) h->cur_pci ^= 1;
+  h->grid_valid = true;
+  return DSL_OK;
+}
+
+int ensure_grid(dsl_handle* h) { return h->grid_valid ? DSL_OK : build_grid(h, true); }
+
+template <class Launch>
+int by_math(dsl_handle* h, Launch&& l) {
+  if (h->prm.math_mode == DSL_MATH_FAST) l(std::true_type{});
+  else l(std::false_type{});
+  return DSL_OK;
+}
+
+int density_pass(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  CSoa3 p = cpos(h);
+  int rc = timed(h, DSL_K_DENSITY, [&] {
+    by_math(h, [&](auto fast) {
+      hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+                         h->cell_start, p, h->rho, h->pterm);
+    });
+  });
+  if (rc) return rc;
+  h->dens_fresh = true;
+  return DSL_OK;
+}
+
+int force_integrate(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  CSoa3 p = cpos(h), v = cvel(h), f = cfrc(h);
+  const int o = h->cur_pv ^ 1;
+  Soa3 po = mpos(h, o), vo = mvel(h, o);
+  const int uni = h->forces_uniform ? 1 : 0;
+  const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
+  int rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
+    by_math(h, [&](auto fast) {
+      constexpr bool FAST = decltype(fast)::value;
+      dim3 g(grid_for(h->n)), b(kBlock);
+#define DSL_LAUNCH_FI(GG, VV)                                                                                    \
+  hipLaunchKernelGGL((k_force_integrate<FAST, GG, VV>), g, b, 0, h->stream, c, h->cell_start, p, v, h->rho,     \
+                     h->pterm, f, uni, po, vo, h->dstats)
+      if (G && V) DSL_LAUNCH_FI(true, true);
+      else if (G) DSL_LAUNCH_FI(true, false);
+      else if (V) DSL_LAUNCH_FI(false, true);
+      else DSL_LAUNCH_FI(false, false);
+#undef DSL_LAUNCH_FI
+    });
+  });
+  if (rc) return rc;
+  h->cur_pv = o;
+  h->forces_uniform = true;  // Update resets every force to force_reset (fluid.go:193)
+  h->press_zero = true;      // ... and every pressure to 0 (fluid.go:192)
+  h->grid_valid = false;     // positions moved
+  return DSL_OK;
+}
+
+int gradient_pass(dsl_handle* h, int honour_done) {
+  const DevConsts& c = h->c;
+  CSoa3 p = cpos(h);
+  Soa3 f = mfrc(h);
+  return timed(h, DSL_K_GRADIENT, [&] {
+    by_math(h, [&](auto fast) {
+      hipLaunchKernelGGL((k_gradient<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+                         h->cell_start, p, h->rho, h->pterm, f, h->dstats, honour_done);
+    });
+  });
+}
+
+int viscous_pass(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  CSoa3 p = cpos(h), v = cvel(h);
+  Soa3 f = mfrc(h);
+  return timed(h, DSL_K_VISCOUS, [&] {
+    by_math(h, [&](auto fast) {
+      hipLaunchKernelGGL((k_viscous<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+                         h->cell_start, p, v, h->rho, f);
+    });
+  });
+}
+
+int update_pass(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
+  CSoa3 f = cfrc(h);
+  const int uni = h->forces_uniform ? 1 : 0;
+  int rc = timed(h, DSL_K_UPDATE, [&] {
+    hipLaunchKernelGGL(k_update, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c, p, v, f, uni, h->dstats);
+  });
+  if (rc) return rc;
+  h->forces_uniform = true;
+  h->press_zero = true;
+  h->grid_valid = false;
+  return DSL_OK;
+}
+
+struct BufInfo {
+  int comps;
+};
+bool buf_info(int buffer, BufInfo& bi) {
+  switch (buffer) {
+    case DSL_BUF_POSITIONS:
+    case DSL_BUF_VELOCITIES:
+    case DSL_BUF_FORCES:
+    case DSL_BUF_PCI_POSITIONS:
+    case DSL_BUF_PCI_VELOCITIES:
+      bi.comps = 3;
+      return true;
+    case DSL_BUF_DENSITIES:
+    case DSL_BUF_PRESSURES:
+      bi.comps = 1;
+      return true;
+    default:
+      return false;
+  }
+}
+
+void free_all(dsl_handle* h) {
+  for (int w = 0; w < 2; ++w) {
+    for (int k = 0; k < 6; ++k) {
+      (void)hipFree(h->pv[w][k]);
+      (void)hipFree(h->pci[w][k]);
+    }
+    for (int k = 0; k < 3; ++k) (void)hipFree(h->frc[w][k]);
+    (void)hipFree(h->ids[w]);
+  }
+  (void)hipFree(h->rho);
+  (void)hipFree(h->pterm);
+  (void)hipFree(h->press);
+  (void)hipFree(h->scratch1);
+  (void)hipFree(h->cellid);
+  (void)hipFree(h->rank);
+  (void)hipFree(h->cell_count);
+  (void)hipFree(h->cell_start);
+  (void)hipFree(h->block_sums);
+  (void)hipFree(h->stage);
+  (void)hipFree(h->dstats);
+  for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
+  for (auto& v : h->pending)
+    for (auto& pr : v) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+}
+
+int alloc_pci(dsl_handle* h) {
+  if (h->pci[0][0]) return DSL_OK;
+  for (int w = 0; w < 2; ++w)
+    for (int k = 0; k < 6; ++k)
+      if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->n)) return rc;
+  return DSL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsl_version(void) { return "dslsph 0.1 (gfx950)"; }
+
+const char* dsl_last_error(dsl_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dsl_params_reference(dsl_params* p, int n3) {
+  if (!p || n3 <= 0) return fail(nullptr, DSL_ERR_INVALID, "dsl_params_reference: bad argument");
+  std::memset(p, 0, sizeof(*p));
+  p->struct_size = sizeof(dsl_params);
+  p->abi_version = DSL_ABI_VERSION;
+  const int num = n3 * n3 * n3;                  // fluid.go:51
+  p->n_particles = num;
+  p->n_boundary = 0;
+  p->lsh_buckets = 255;                          // fluid.go:64
+  p->lsh_bucket_size = (int)((float)(num / 255) * 1.5f);  // lsh.go:33
+  p->dt = 0.01f;                                 // fluid.go:112
+  p->mass = 1.0f;                                // fluid.go:56
+  p->delta = 0.0f;
+  p->max_vel = 0.0f;
+  p->h = 1.0f;                                   // fluid.go:48
+  p->ref_density = (float)num / 8.0f;            // fluid.go:55, point-grid.go:44-46
+  p->mu = 1.3059f;                               // fluid.go:18
+  p->eos_w = 2.15f;                              // model.go:94
+  p->eos_gamma = 7.16f;                          // model.go:93
+  p->eos_d0_grad = 87.0f;                        // model.go:41
+  p->pressure_sign = 1.0f;
+  p->visc_running_mass = 1;
+  p->force_reset[1] = -9.81f * p->mass;          // fluid.go:193
+  p->external[1] = -9.81f;                       // wcsph.go:19
+  p->pci_max_iters = 5;                          // pcisph_darwin.go:49
+  p->pci_max_error = 0.01f;                      // pcisph_darwin.go:50
+  for (int a = 0; a < 3; ++a) {
+    p->box_min[a] = -1.0f;
+    p->box_max[a] = 1.0f;
+    p->grid_min[a] = -4.0f;
+    p->grid_max[a] = 4.0f;
+  }
+  p->neigh_mode = DSL_NEIGH_GRID;
+  p->math_mode = DSL_MATH_EXACT;
+  return DSL_OK;
+}
+
+int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
+  if (!params || !out) return fail(nullptr, DSL_ERR_INVALID, "dsl_create: null argument");
+  *out = nullptr;
+  if (params->struct_size != sizeof(dsl_params) || params->abi_version != DSL_ABI_VERSION)
+    return fail(nullptr, DSL_ERR_INVALID, "dsl_create: dsl_params size/version mismatch (use dsl_params_reference)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, DSL_ERR_DEVICE, "dsl_create: no HIP device available (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(nullptr, DSL_ERR_INVALID, "dsl_create: device ordinal out of range");
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, DSL_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  dsl_handle* h = new (std::nothrow) dsl_handle();
+  if (!h) return fail(nullptr, DSL_ERR_NOMEM, "dsl_create: out of host memory");
+  h->device = device;
+  h->prm = *params;
+  int rc = make_consts(h, h->prm, h->c);
+  if (rc) {
+    g_create_error = h->err;
+    delete h;
+    return rc;
+  }
+  h->n = h->c.n;
+  h->ncell = h->c.ncell;
+  h->ncell_pad = ((h->ncell + 1 + kScanTile - 1) / kScanTile) * kScanTile;
+  h->nscan = h->ncell_pad / kScanTile;
+  const size_t n = (size_t)h->n;
+  auto bail = [&](int code) {
+    g_create_error = h->err;
+    free_all(h);
+    delete h;
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    h->err = "hipStreamCreate failed";
+    return bail(DSL_ERR_DEVICE);
+  }
+  h->stream = h->own_stream;
+  for (int w = 0; w < 2; ++w) {
+    for (int k = 0; k < 6; ++k)
+      if ((rc = dev_alloc(h, &h->pv[w][k], n))) return bail(rc);
+    for (int k = 0; k < 3; ++k)
+      if ((rc = dev_alloc(h, &h->frc[w][k], n))) return bail(rc);
+    if ((rc = dev_alloc(h, &h->ids[w], n))) return bail(rc);
+  }
+  if ((rc = dev_alloc(h, &h->rho, n)) || (rc = dev_alloc(h, &h->pterm, n)) || (rc = dev_alloc(h, &h->press, n)) ||
+      (rc = dev_alloc(h, &h->scratch1, n)) || (rc = dev_alloc(h, &h->cellid, n)) || (rc = dev_alloc(h, &h->rank, n)) ||
+      (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
+      (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
+      (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
+      (rc = dev_alloc(h, &h->dstats, 1)))
+    return bail(rc);
+  // NewParticleArray zero-fills every slice (particle_array.go:18-33)
+  hipError_t me = hipSuccess;
+  for (int k = 0; k < 6 && me == hipSuccess; ++k) me = hipMemsetAsync(h->pv[0][k], 0, n * sizeof(float), h->stream);
+  for (int k = 0; k < 3 && me == hipSuccess; ++k) me = hipMemsetAsync(h->frc[0][k], 0, n * sizeof(float), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(h->rho, 0, n * sizeof(float), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(h->pterm, 0, n * sizeof(float), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(h->press, 0, n * sizeof(float), h->stream);
+  if (me == hipSuccess) me = hipMemsetAsync(h->dstats, 0, sizeof(DevStats), h->stream);
+  if (me != hipSuccess) {
+    h->err = std::string("hipMemsetAsync: ") + hipGetErrorString(me);
+    return bail(DSL_ERR_DEVICE);
+  }
+  hipLaunchKernelGGL(k_iota, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->n, h->ids[0]);
+  DevStats init{};
+  init.max_vel_bits = params->max_vel > 0.f ? *reinterpret_cast<const unsigned int*>(&params->max_vel) : 0u;
+  if (hipMemcpyAsync(h->dstats, &init, sizeof(init), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess) {
+    h->err = "device initialisation failed";
+    return bail(DSL_ERR_DEVICE);
+  }
+  h->forces_uniform = false;  // uploaded / zero forces are honoured until the first Update
+  h->press_zero = true;
+  *out = h;
+  return DSL_OK;
+}
+
+int dsl_destroy(dsl_handle* h) {
+  if (!h) return DSL_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  free_all(h);
+  delete h;
+  return DSL_OK;
+}
+
+int dsl_set_params(dsl_handle* h, const dsl_params* p) {
+  CHECK_HANDLE(h);
+  if (!p || p->struct_size != sizeof(dsl_params) || p->abi_version != DSL_ABI_VERSION)
+    return fail(h, DSL_ERR_INVALID, "dsl_set_params: dsl_params size/version mismatch");
+  DevConsts c{};
+  if (int rc = make_consts(h, *p, c)) return rc;
+  if (c.n != h->c.n || c.ncell != h->c.ncell || c.dims[0] != h->c.dims[0] || c.dims[1] != h->c.dims[1] ||
+      c.dims[2] != h->c.dims[2] || c.h != h->c.h)
+    return fail(h, DSL_ERR_INVALID, "dsl_set_params: n_particles, h and the grid box are fixed at creation");
+  if (std::memcmp(c.reset, h->c.reset, sizeof(c.reset)) != 0 && h->forces_uniform) {
+    if (int rc = materialise_forces(h)) return rc;  // keep the old implicit value
+  }
+  h->prm = *p;
+  h->c = c;
+  return DSL_OK;
+}
+
+int dsl_get_params(dsl_handle* h, dsl_params* out) {
+  CHECK_HANDLE(h);
+  if (!out) return fail(h, DSL_ERR_INVALID, "null out");
+  *out = h->prm;
+  return DSL_OK;
+}
+
+int dsl_set_stream(dsl_handle* h, void* s) {
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return DSL_OK;
+}
+
+int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
+  CHECK_HANDLE(h);
+  BufInfo bi;
+  if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_upload: bad buffer id or null pointer");
+  const size_t n = (size_t)h->n;
+  if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_upload: count does not match the buffer size");
+  HIP_TRY(h, hipMemcpyAsync(h->stage, host, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const int* ids = h->ids[h->cur_ids];
+  dim3 g(grid_for(h->n)), b(kBlock);
+  switch (buffer) {
+    case DSL_BUF_POSITIONS: {
+      Soa3 p = mpos(h, h->cur_pv);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, p.x, p.y, p.z);
+      h->grid_valid = false;
+      break;
+    }
+    case DSL_BUF_VELOCITIES: {
+      Soa3 v = mvel(h, h->cur_pv);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, v.x, v.y, v.z);
+      break;
+    }
+    case DSL_BUF_FORCES: {
+      Soa3 f = mfrc(h);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, f.x, f.y, f.z);
+      h->forces_uniform = false;
+      break;
+    }
+    case DSL_BUF_DENSITIES:
+      hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->rho);
+      // pterm must follow an uploaded density
+      by_math(h, [&](auto fast) {
+        hipLaunchKernelGGL((k_pterm<decltype(fast)::value>), g, b, 0, h->stream, h->c, h->rho, h->pterm);
+      });
+      h->dens_fresh = true;
+      break;
+    case DSL_BUF_PRESSURES:
+      hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->press);
+      h->press_zero = false;
+      break;
+    case DSL_BUF_PCI_POSITIONS:
+    case DSL_BUF_PCI_VELOCITIES: {
+      if (int rc = alloc_pci(h)) return rc;
+      if (!h->pci_active) {
+        // pcisph_darwin.go:28-41: the state starts as a copy of positions/velocities
+        for (int k = 0; k < 6; ++k)
+          HIP_TRY(h, hipMemcpyAsync(h->pci[h->cur_pci][k], h->pv[h->cur_pv][k], n * sizeof(float),
+                                    hipMemcpyDeviceToDevice, h->stream));
+        h->pci_active = true;
+      }
+      Soa3 d = buffer == DSL_BUF_PCI_POSITIONS ? mpcip(h) : mpciv(h);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, d.x, d.y, d.z);
+      break;
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // host pointer is not retained (cgo rule)
+  return DSL_OK;
+}
+
+static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, int sorted_order) {
+  CHECK_HANDLE(h);
+  BufInfo bi;
+  if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_download: bad buffer id or null pointer");
+  const size_t n = (size_t)h->n;
+  if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_download: count does not match the buffer size");
+  const int* ids = h->ids[h->cur_ids];
+  dim3 g(grid_for(h->n)), b(kBlock);
+  switch (buffer) {
+    case DSL_BUF_POSITIONS: {
+      CSoa3 p = cpos(h);
+      hipLaunchKernelGGL(k_pack3, g, b, 0, h->stream, h->n, h->stage, ids, p.x, p.y, p.z, sorted_order);
+      break;
+    }
+    case DSL_BUF_VELOCITIES: {
+      CSoa3 v = cvel(h);
+      hipLaunchKernelGGL(k_pack3, g, b, 0, h->stream, h->n, h->stage, ids, v.x, v.y, v.z, sorted_order);
+      break;
+    }
+    case DSL_BUF_FORCES: {
+      if (int rc = materialise_forces(h)) return rc;
+      CSoa3 f = cfrc(h);
+      hipLaunchKernelGGL(k_pack3, g, b, 0, h->stream, h->n, h->stage, ids, f.x, f.y, f.z, sorted_order);
+      break;
+    }
+    case DSL_BUF_DENSITIES:
+      hipLaunchKernelGGL(k_pack1, g, b, 0, h->stream, h->n, h->stage, ids, h->rho, sorted_order);
+      break;
+    case DSL_BUF_PRESSURES:
+      if (int rc = materialise_press(h)) return rc;
+      hipLaunchKernelGGL(k_pack1, g, b, 0, h->stream, h->n, h->stage, ids, h->press, sorted_order);
+      break;
+    case DSL_BUF_PCI_POSITIONS:
+    case DSL_BUF_PCI_VELOCITIES: {
+      if (!h->pci_active) return fail(h, DSL_ERR_INVALID, "dsl_download: PCISPH state not initialised (dsl_pcisph_begin)");
+      Soa3 s = buffer == DSL_BUF_PCI_POSITIONS ? mpcip(h) : mpciv(h);
+      hipLaunchKernelGGL(k_pack3, g, b, 0, h->stream, h->n, h->stage, ids, s.x, s.y, s.z, sorted_order);
+      break;
+    }
+  }
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host, h->stage, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+int dsl_download(dsl_handle* h, int buffer, float* host, size_t count) {
+  return download_impl(h, buffer, host, count, 0);
+}
+int dsl_download_sorted(dsl_handle* h, int buffer, float* host, size_t count) {
+  return download_impl(h, buffer, host, count, 1);
+}
+int dsl_download_ids(dsl_handle* h, int32_t* ids, size_t count) {
+  CHECK_HANDLE(h);
+  if (!ids || count != (size_t)h->n) return fail(h, DSL_ERR_INVALID, "dsl_download_ids: bad argument");
+  HIP_TRY(h, hipMemcpyAsync(ids, h->ids[h->cur_ids], count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+int dsl_download_cell_start(dsl_handle* h, int32_t* cs, size_t count) {
+  CHECK_HANDLE(h);
+  if (!cs || count != (size_t)h->ncell + 1) return fail(h, DSL_ERR_INVALID, "dsl_download_cell_start: count must be cells+1");
+  if (!h->grid_valid) return fail(h, DSL_ERR_INVALID, "dsl_download_cell_start: neighbour table is stale");
+  HIP_TRY(h, hipMemcpyAsync(cs, h->cell_start, count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+int dsl_build_neighbours(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  return build_grid(h, true);
+}
+
+int dsl_density_pass(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (int rc = ensure_grid(h)) return rc;
+  return density_pass(h);
+}
+
+int dsl_pressure_pass(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  const DevConsts& c = h->c;
+  int rc = timed(h, DSL_K_PRESSURE, [&] {
+    by_math(h, [&](auto fast) {
+      hipLaunchKernelGGL((k_pressure<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+                         h->rho, h->press);
+    });
+  });
+  if (rc) return rc;
+  h->press_zero = false;
+  return DSL_OK;
+}
+
+int dsl_viscous_pass(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (int rc = ensure_grid(h)) return rc;
+  if (int rc = materialise_forces(h)) return rc;
+  return viscous_pass(h);
+}
+
+int dsl_external_pass(dsl_handle* h, const float f[3]) {
+  CHECK_HANDLE(h);
+  if (!f) return fail(h, DSL_ERR_INVALID, "null force");
+  if (int rc = materialise_forces(h)) return rc;
+  Soa3 F = mfrc(h);
+  return timed(h, DSL_K_EXTERNAL, [&] {
+    hipLaunchKernelGGL(k_external, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->n, F, f[0], f[1], f[2]);
+  });
+}
+
+int dsl_gradient_pressure_pass(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (int rc = ensure_grid(h)) return rc;
+  if (int rc = materialise_forces(h)) return rc;
+  return gradient_pass(h, 0);
+}
+
+int dsl_update_pass(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  return update_pass(h);
+}
+
+int dsl_force_pass(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (int rc = ensure_grid(h)) return rc;
+  return force_integrate(h);
+}
+
+int dsl_wcsph_step(dsl_handle* h, int nsteps) {
+  CHECK_HANDLE(h);
+  for (int s = 0; s < nsteps; ++s) {
+    if (int rc = build_grid(h, false)) return rc;  // NN(): geometric neighbour rule -> every step
+    if (int rc = density_pass(h)) return rc;        // DensityAll   wcsph.go:18
+    if (int rc = force_integrate(h)) return rc;     // ExternalAll, PressureAll, Update wcsph.go:19-21
+    h->steps++;
+  }
+  return DSL_OK;
+}
+
+int dsl_pcisph_begin(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (int rc = alloc_pci(h)) return rc;
+  const size_t n = (size_t)h->n;
+  for (int k = 0; k < 6; ++k)
+    HIP_TRY(h, hipMemcpyAsync(h->pci[h->cur_pci][k], h->pv[h->cur_pv][k], n * sizeof(float), hipMemcpyDeviceToDevice,
+                              h->stream));
+  h->pci_active = true;
+  return DSL_OK;
+}
+
+int dsl_pcisph_step(dsl_handle* h, int nsteps) {
+  CHECK_HANDLE(h);
+  if (!h->pci_active) {
+    if (int rc = dsl_pcisph_begin(h)) return rc;
+  }
+  const DevConsts& c = h->c;
+  dim3 g(grid_for(h->n)), b(kBlock);
+  for (int s = 0; s < nsteps; ++s) {
+    if (int rc = build_grid(h, false)) return rc;
+    if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
+    if (int rc = materialise_forces(h)) return rc;
+    if (int rc = materialise_press(h)) return rc;
+    if (int rc = viscous_pass(h)) return rc;        // ViscousAll  :45
+    hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats);
+    for (int it = 0; it < h->prm.pci_max_iters; ++it) {
+      CSoa3 p = cpos(h), f = cfrc(h);
+      Soa3 pp = mpcip(h), pvv = mpciv(h);
+      int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
+        hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, f, pp, pvv, h->dstats);
+      });
+      if (rc) return rc;
+      CSoa3 cpp{pp.x, pp.y, pp.z};
+      rc = timed(h, DSL_K_PCI_DENSITY, [&] {
+        by_math(h, [&](auto fast) {
+          hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, h->cell_start, p, cpp,
+                             h->press, h->dstats);
+        });
+      });
+      if (rc) return rc;
+      if ((rc = gradient_pass(h, 1))) return rc;    // GradientPressureForce :93
+      hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, c, h->dstats);
+    }
+    HIP_TRY(h, hipGetLastError());
+    if (int rc = update_pass(h)) return rc;         // Update :101
+    h->steps++;
+  }
+  return DSL_OK;
+}
+
+int dsl_get_stats(dsl_handle* h, dsl_stats* out) {
+  CHECK_HANDLE(h);
+  if (!out) return fail(h, DSL_ERR_INVALID, "null out");
+  DevStats d{};
+  HIP_TRY(h, hipMemcpyAsync(&d, h->dstats, sizeof(d), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::memcpy(&out->max_vel, &d.max_vel_bits, 4);
+  std::memcpy(&out->max_f, &d.max_f_bits, 4);
+  std::memcpy(&out->pci_max_error, &d.pci_last_err_bits, 4);
+  out->pci_iters = d.pci_iters;
+  out->steps = h->steps;
+  for (int a = 0; a < 3; ++a) out->grid_dims[a] = h->c.dims[a];
+  out->grid_cells = h->c.ncell;
+  out->max_cell_count = d.max_cell_count;
+  return DSL_OK;
+}
+
+int dsl_sync(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+int dsl_timing_enable(dsl_handle* h, int on) {
+  CHECK_HANDLE(h);
+  h->timing = on != 0;
+  return DSL_OK;
+}
+int dsl_timing_reset(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (int rc = drain_timing(h)) return rc;
+  for (int k = 0; k < DSL_K_COUNT; ++k) {
+    h->total_ms[k] = 0.0;
+    h->launches[k] = 0;
+  }
+  return DSL_OK;
+}
+int dsl_timing_get(dsl_handle* h, int kid, double* avg_ms, int64_t* launches) {
+  CHECK_HANDLE(h);
+  if (kid < 0 || kid >= DSL_K_COUNT) return fail(h, DSL_ERR_INVALID, "bad kernel id");
+  if (int rc = drain_timing(h)) return rc;
+  if (avg_ms) *avg_ms = h->launches[kid] ? h->total_ms[kid] / (double)h->launches[kid] : 0.0;
+  if (launches) *launches = h->launches[kid];
+  return DSL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// kernels_grid.hpp -- uniform-grid neighbour table built by a GPU counting sort:
+//   k_cell_rank  : cell hash + wave-aggregated histogram (segmented by __ballot)
+//   k_scan_*     : exclusive prefix sum of the cell histogram, wavefront scan
+//                  (__shfl_up) staged through LDS, three phases
+//   k_scatter    : counting-sort scatter of the SoA particle arrays
+// Replaces sampler/lsh (sampler/lsh/lsh.go:102-133) as the neighbour structure, as
+// BASELINE.json's north_star asks; gfx950 only.
+#pragma once
+
+#include "sph_device.hpp"
+
+namespace dsl {
+
+constexpr int kBlock = 256;
+constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lanes x int4
+
+// ---------------------------------------------------------------------------------
+// cell hash + rank inside the cell.  Consecutive lanes usually hold particles of the
+// same cell (the input is the previous step's sorted order), so equal-cell runs are
+// found with one ballot and only the run's first lane issues the atomic.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* __restrict__ px,
+                                                      const float* __restrict__ py,
+                                                      const float* __restrict__ pz, int* __restrict__ cellid,
+                                                      int* __restrict__ rank, int* __restrict__ cell_count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  int cell = -1;
+  if (i < c.n) cell = cell_of(c, px[i], py[i], pz[i]);
+  const int prev = __shfl_up(cell, 1, kWave);
+  const bool head = (lane == 0) || (cell != prev);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long le = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  const int head_lane = 63 - __builtin_clzll(le);  // le always has bit 0 set
+  const unsigned long long above = (head_lane == 63) ? 0ull : (heads & ~((2ull << head_lane) - 1ull));
+  const int next = above ? __builtin_ctzll(above) : kWave;
+  const int run = next - head_lane;
+  int base = 0;
+  if (lane == head_lane && cell >= 0) base = atomicAdd(&cell_count[cell], run);
+  base = __shfl(base, head_lane, kWave);
+  if (i < c.n) {
+    cellid[i] = cell;
+    rank[i] = base + (lane - head_lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// prefix sum
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+  const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    int t = __shfl_up(v, o, kWave);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; lds holds 4 wave sums
+__device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wid = threadIdx.x >> 6;
+  const int inc = wave_inclusive_scan(v);
+  if (lane == kWave - 1) lds[wid] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    const int s = lds[w];
+    if (w < wid) off += s;
+    tot += s;
+  }
+  __syncthreads();
+  total = tot;
+  return off + inc - v;
+}
+
+// phase 1: one sum per 4096-cell tile
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ count, int* __restrict__ block_sums) {
+  __shared__ int lds[kBlock / kWave];
+  const int4* src = reinterpret_cast<const int4*>(count + (size_t)blockIdx.x * kScanTile);
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int4 v = src[k * kBlock + threadIdx.x];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  int total;
+  block_exclusive_scan(s, lds, total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// phase 2: exclusive scan of the tile sums in place (single block)
+__global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sums, int nb) {
+  __shared__ int lds[kBlock / kWave];
+  int carry = 0;
+  for (int base = 0; base < nb; base += kBlock) {
+    const int idx = base + threadIdx.x;
+    const int v = idx < nb ? block_sums[idx] : 0;
+    int total;
+    const int ex = block_exclusive_scan(v, lds, total);
+    if (idx < nb) block_sums[idx] = carry + ex;
+    carry += total;
+  }
+}
+
+// phase 3: exclusive scan inside each tile + tile offset; also tracks the fullest cell
+__global__ __launch_bounds__(kBlock) void k_scan_apply(const int* __restrict__ count,
+                                                       const int* __restrict__ block_sums,
+                                                       int* __restrict__ cell_start, DevStats* stats) {
+  __shared__ int lds[kBlock / kWave];
+  const int4* src = reinterpret_cast<const int4*>(count + (size_t)blockIdx.x * kScanTile);
+  int4* dst = reinterpret_cast<int4*>(cell_start + (size_t)blockIdx.x * kScanTile);
+  int carry = block_sums[blockIdx.x];
+  int mx = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int4 v = src[k * kBlock + threadIdx.x];
+    mx = max(max(mx, max(v.x, v.y)), max(v.z, v.w));
+    const int s = (v.x + v.y) + (v.z + v.w);
+    int total;
+    const int ex = carry + block_exclusive_scan(s, lds, total);
+    int4 o;
+    o.x = ex;
+    o.y = ex + v.x;
+    o.z = o.y + v.y;
+    o.w = o.z + v.z;
+    dst[k * kBlock + threadIdx.x] = o;
+    carry += total;
+  }
+  for (int off = kWave / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, kWave));
+  if ((threadIdx.x & (kWave - 1)) == 0 && mx > 0) atomicMax(&stats->max_cell_count, mx);
+}
+
+// ---------------------------------------------------------------------------------
+// counting-sort scatter of every live SoA array (positions, velocities, and when they
+// are materialised the forces and the PCISPH predictor state) plus the slot->particle map
+// ---------------------------------------------------------------------------------
+constexpr int kMaxScatter = 16;
+struct ScatterArrays {
+  const float* src[kMaxScatter];
+  float* dst[kMaxScatter];
+  int nf;
+  const int* ids_src;
+  int* ids_dst;
+};
+
+__global__ __launch_bounds__(kBlock) void k_scatter(int n, ScatterArrays a, const int* __restrict__ cellid,
+                                                    const int* __restrict__ rank,
+                                                    const int* __restrict__ cell_start) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int d = cell_start[cellid[i]] + rank[i];
+  a.ids_dst[d] = a.ids_src[i];
+  for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
+}
+
+// ---------------------------------------------------------------------------------
+// host <-> device layout conversion: the reference keeps xyz interleaved on the host
+// (model/particle_array.go:5-15); the device keeps SoA in cell-sorted order with
+// ids[slot] = original particle index.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_unpack3(int n, const float* __restrict__ stage, const int* __restrict__ ids,
+                                                    float* __restrict__ x, float* __restrict__ y,
+                                                    float* __restrict__ z) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  const int o = ids[s];
+  x[s] = stage[3 * o];
+  y[s] = stage[3 * o + 1];
+  z[s] = stage[3 * o + 2];
+}
+__global__ __launch_bounds__(kBlock) void k_unpack1(int n, const float* __restrict__ stage, const int* __restrict__ ids,
+                                                    float* __restrict__ x) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  x[s] = stage[ids[s]];
+}
+__global__ __launch_bounds__(kBlock) void k_pack3(int n, float* __restrict__ stage, const int* __restrict__ ids,
+                                                  const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ z, int sorted_order) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  const int o = sorted_order ? s : ids[s];
+  stage[3 * o] = x[s];
+  stage[3 * o + 1] = y[s];
+  stage[3 * o + 2] = z[s];
+}
+__global__ __launch_bounds__(kBlock) void k_pack1(int n, float* __restrict__ stage, const int* __restrict__ ids,
+                                                  const float* __restrict__ x, int sorted_order) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  stage[sorted_order ? s : ids[s]] = x[s];
+}
+__global__ __launch_bounds__(kBlock) void k_iota(int n, int* __restrict__ ids) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s < n) ids[s] = s;
+}
+__global__ __launch_bounds__(kBlock) void k_fill3(int n, float* __restrict__ x, float* __restrict__ y,
+                                                  float* __restrict__ z, float vx, float vy, float vz) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  x[s] = vx;
+  y[s] = vy;
+  z[s] = vz;
+}
+
+}  // namespace dsl

@@ -1,0 +1,401 @@
+// kernels_sph.hpp -- the SPH passes of model/sph/fluid.go as gfx950 kernels over the
+// cell-sorted SoA arrays.  One lane per particle slot; the neighbour sweep walks the
+// nine x-runs of the 27 surrounding cells (sph_device.hpp).  All passes are Jacobi:
+// they read state the pass itself never writes (the fused force+integrate kernel writes
+// the other half of the ping-pong pair).
+#pragma once
+
+#include "kernels_grid.hpp"
+
+namespace dsl {
+
+struct Soa3 {
+  float *x, *y, *z;
+};
+struct CSoa3 {
+  const float *x, *y, *z;
+};
+
+// ---------------------------------------------------------------------------------
+// D: SPHField.Density (model/field/sph_field.go:155-172) for every slot, plus the
+// per-particle pressure term P(rho)/rho^2 of SPHField.Gradient (sph_field.go:192-196,
+// field_types.go:39-42) so the force sweep does not call pow per neighbour.
+// ---------------------------------------------------------------------------------
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_density(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+                                                    float* __restrict__ rho, float* __restrict__ pterm) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= c.n) return;
+  const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
+  float density = 0.0f;
+  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+    if (j == i) return;
+    const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+    const float r2 = dist2<FAST>(dx, dy, dz);
+    if constexpr (FAST) {
+      if (r2 < c.hh) {
+        const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+        density = __builtin_fmaf(c.mass * c.A, q * q, density);
+      }
+    } else {
+      const float dist = dsl_sqrt<false>(r2);
+      if (dist < c.h) {
+        const float w = kern_F<false>(c, dist);
+        density += c.mass * w;
+      }
+    }
+  });
+  rho[i] = density;
+  const float pr = tait_eos<FAST>(c, density, c.eos_d0_grad);
+  pterm[i] = dsl_div<FAST>(pr, density * density);
+}
+
+// PR: SPH.PressureAll (fluid.go:134-142): Press = TaitEos(rho, D0, 0)
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_pressure(DevConsts c, const float* __restrict__ rho,
+                                                     float* __restrict__ press) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= c.n) return;
+  press[i] = tait_eos<FAST>(c, rho[i], c.ref_density);
+}
+
+// P(rho)/rho^2 for densities that arrive by upload instead of from k_density
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_pterm(DevConsts c, const float* __restrict__ rho,
+                                                  float* __restrict__ pterm) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= c.n) return;
+  const float d = rho[i];
+  pterm[i] = dsl_div<FAST>(tait_eos<FAST>(c, d, c.eos_d0_grad), d * d);
+}
+
+// ---------------------------------------------------------------------------------
+// Shared neighbour sweep for G (sph_field.go:175-200) and V (sph_field.go:251-269).
+// accG accumulates grad*(Pi/rho_i^2 + Pj/rho_j^2); accV is LaplacianForce's running sum.
+// ---------------------------------------------------------------------------------
+template <bool FAST, bool WANT_G, bool WANT_V>
+__device__ __forceinline__ void force_sweep(const DevConsts& c, const int* __restrict__ cell_start, int i,
+                                            const CSoa3& p, const CSoa3& v, const float* __restrict__ rho,
+                                            const float* __restrict__ pterm, float accG[3], float accV[3]) {
+  const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
+  float vxi = 0.f, vyi = 0.f, vzi = 0.f, pti = 0.f;
+  if constexpr (WANT_V) {
+    vxi = v.x[i];
+    vyi = v.y[i];
+    vzi = v.z[i];
+  }
+  if constexpr (WANT_G) pti = pterm[i];
+  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+    if (j == i) return;
+    // dir = x_j - x_i (sph_field.go:189); |x_i - x_j| has the same squares
+    const float dx = p.x[j] - xi, dy = p.y[j] - yi, dz = p.z[j] - zi;
+    const float r2 = dist2<FAST>(dx, dy, dz);
+    if constexpr (FAST) {
+      if (!(r2 < c.hh)) return;
+      const float rinv = __builtin_amdgcn_rsqf(r2);  // r2 == 0 -> inf, handled below
+      const float dist = r2 * rinv;
+      const float q = __builtin_fmaf(-(r2 > 0.f ? dist : 0.f), c.inv_h, 1.0f);
+      if constexpr (WANT_G) {
+        const float s = -(c.B * q) * q;  // -O1D
+        const float F = pti + pterm[j];
+        const float k = (r2 > 0.f) ? s * F * rinv : 0.0f;  // Norm() of a zero vector is zero
+        accG[0] = __builtin_fmaf(dx, k, accG[0]);
+        accG[1] = __builtin_fmaf(dy, k, accG[1]);
+        accG[2] = __builtin_fmaf(dz, k, accG[2]);
+      }
+      if constexpr (WANT_V) {
+        const float w = (c.C * q) * __builtin_amdgcn_rcpf(rho[j]);
+        if (c.visc_running_mass) {
+          accV[0] = __builtin_fmaf(v.x[j] - vxi, w, accV[0]) * c.mass;
+          accV[1] = __builtin_fmaf(v.y[j] - vyi, w, accV[1]) * c.mass;
+          accV[2] = __builtin_fmaf(v.z[j] - vzi, w, accV[2]) * c.mass;
+        } else {
+          const float wm = w * c.mass;
+          accV[0] = __builtin_fmaf(v.x[j] - vxi, wm, accV[0]);
+          accV[1] = __builtin_fmaf(v.y[j] - vyi, wm, accV[1]);
+          accV[2] = __builtin_fmaf(v.z[j] - vzi, wm, accV[2]);
+        }
+      }
+    } else {
+      const float dist = dsl_sqrt<false>(r2);
+      if (!(dist < c.h)) return;
+      if constexpr (WANT_G) {
+        float nx = 0.f, ny = 0.f, nz = 0.f;  // vector.go:322-331 Norm
+        if (dist != 0.0f) {
+          nx = dx / dist;
+          ny = dy / dist;
+          nz = dz / dist;
+        }
+        const float s = -kern_O1D<false>(c, dist);  // std_kernel.go:74-76 Grad
+        const float gx = nx * s, gy = ny * s, gz = nz * s;
+        const float F = pti + pterm[j];
+        const float tx = gx * F, ty = gy * F, tz = gz * F;
+        accG[0] = accG[0] + tx;
+        accG[1] = accG[1] + ty;
+        accG[2] = accG[2] + tz;
+      }
+      if constexpr (WANT_V) {
+        const float inv = 1.0f / rho[j];
+        const float ux = (v.x[j] - vxi) * inv, uy = (v.y[j] - vyi) * inv, uz = (v.z[j] - vzi) * inv;
+        const float o2 = kern_O2D<false>(c, dist);
+        const float tx = ux * o2, ty = uy * o2, tz = uz * o2;
+        if (c.visc_running_mass) {  // sph_field.go:265: (force + t) * m
+          const float sx = accV[0] + tx, sy = accV[1] + ty, sz = accV[2] + tz;
+          accV[0] = sx * c.mass;
+          accV[1] = sy * c.mass;
+          accV[2] = sz * c.mass;
+        } else {
+          const float mx = tx * c.mass, my = ty * c.mass, mz = tz * c.mass;
+          accV[0] = accV[0] + mx;
+          accV[1] = accV[1] + my;
+          accV[2] = accV[2] + mz;
+        }
+      }
+    }
+  });
+}
+
+// G: SPH.GradientPressureForce (fluid.go:164-172): F_i += sign * rho_i*m * accG
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+                                                     const float* __restrict__ rho, const float* __restrict__ pterm,
+                                                     Soa3 f, const DevStats* stats, int honour_done) {
+  if (honour_done && stats->pci_done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= c.n) return;
+  float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
+  CSoa3 nov{nullptr, nullptr, nullptr};
+  force_sweep<FAST, true, false>(c, cell_start, i, p, nov, rho, pterm, accG, accV);
+  const float dm = rho[i] * c.mass;
+  const float gx = accG[0] * dm, gy = accG[1] * dm, gz = accG[2] * dm;
+  const float sx = gx * c.pressure_sign, sy = gy * c.pressure_sign, sz = gz * c.pressure_sign;
+  f.x[i] += sx;
+  f.y[i] += sy;
+  f.z[i] += sz;
+}
+
+// V: SPH.ViscousAll (fluid.go:146-152): F_i += mu * LaplacianForce(i)
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, const int* __restrict__ cell_start, CSoa3 p, CSoa3 v,
+                                                    const float* __restrict__ rho, Soa3 f) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= c.n) return;
+  float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
+  force_sweep<FAST, false, true>(c, cell_start, i, p, v, rho, nullptr, accG, accV);
+  const float tx = accV[0] * c.mu, ty = accV[1] * c.mu, tz = accV[2] * c.mu;
+  f.x[i] += tx;
+  f.y[i] += ty;
+  f.z[i] += tz;
+}
+
+// X: SPH.ExternalAll (fluid.go:155-161)
+__global__ __launch_bounds__(kBlock) void k_external(int n, Soa3 f, float ex, float ey, float ez) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  f.x[i] += ex;
+  f.y[i] += ey;
+  f.z[i] += ez;
+}
+
+// U: SPH.Update (fluid.go:175-197) for one particle, then the build-defined wall box.
+__device__ __forceinline__ void integrate_one(const DevConsts& c, float fx, float fy, float fz, float& px, float& py,
+                                              float& pz, float& vx, float& vy, float& vz, DevStats* stats) {
+  const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
+  const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
+  vx += dvx;
+  vy += dvy;
+  vz += dvz;
+  const float dpx = vx * c.dt, dpy = vy * c.dt, dpz = vz * c.dt;
+  px += dpx;
+  py += dpy;
+  pz += dpz;
+  const float vm = dsl_sqrt<false>(dist2<false>(vx, vy, vz));
+  const float fm = dsl_sqrt<false>(dist2<false>(fx, fy, fz));
+  wave_atomic_max(&stats->max_vel_bits, nonneg_bits(vm));
+  wave_atomic_max(&stats->max_f_bits, nonneg_bits(fm));
+  if (c.walls) {
+    float* P[3] = {&px, &py, &pz};
+    float* V[3] = {&vx, &vy, &vz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (*P[a] < c.bmin[a]) {
+        *P[a] = c.bmin[a];
+        if (*V[a] < 0.0f) *V[a] = -*V[a] * c.rest;
+      }
+      if (*P[a] > c.bmax[a]) {
+        *P[a] = c.bmax[a];
+        if (*V[a] > 0.0f) *V[a] = -*V[a] * c.rest;
+      }
+    }
+  }
+}
+
+// stand-alone Update: in place (per-particle, no neighbour reads)
+__global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, CSoa3 f, int forces_uniform,
+                                                   DevStats* stats) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  float fx = c.reset[0], fy = c.reset[1], fz = c.reset[2];
+  float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+  const bool live = i < c.n;
+  if (live) {
+    if (!forces_uniform) {
+      fx = f.x[i];
+      fy = f.y[i];
+      fz = f.z[i];
+    }
+    px = p.x[i];
+    py = p.y[i];
+    pz = p.z[i];
+    vx = v.x[i];
+    vy = v.y[i];
+    vz = v.z[i];
+  } else {
+    fx = fy = fz = 0.f;
+  }
+  integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats);
+  if (live) {
+    p.x[i] = px;
+    p.y[i] = py;
+    p.z[i] = pz;
+    v.x[i] = vx;
+    v.y[i] = vy;
+    v.z[i] = vz;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Fused WCSPH force + integrate: [G] [V] X (PR) U of one step in one neighbour sweep.
+// Reads the sorted state (pin, vin, rho, pterm, optional forces), writes new positions
+// and velocities to the other half of the ping-pong pair.  PressureAll's result is
+// overwritten by Update (Press = 0, fluid.go:192) so it is not materialised.
+// ---------------------------------------------------------------------------------
+template <bool FAST, bool WANT_G, bool WANT_V>
+__global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const int* __restrict__ cell_start, CSoa3 pin,
+                                                            CSoa3 vin, const float* __restrict__ rho,
+                                                            const float* __restrict__ pterm, CSoa3 fin,
+                                                            int forces_uniform, Soa3 pout, Soa3 vout,
+                                                            DevStats* stats) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool live = i < c.n;
+  float fx = 0.f, fy = 0.f, fz = 0.f, px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+  if (live) {
+    fx = c.reset[0];
+    fy = c.reset[1];
+    fz = c.reset[2];
+    if (!forces_uniform) {
+      fx = fin.x[i];
+      fy = fin.y[i];
+      fz = fin.z[i];
+    }
+    float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
+    if constexpr (WANT_G || WANT_V) force_sweep<FAST, WANT_G, WANT_V>(c, cell_start, i, pin, vin, rho, pterm, accG, accV);
+    if constexpr (WANT_G) {
+      const float dm = rho[i] * c.mass;
+      const float gx = accG[0] * dm, gy = accG[1] * dm, gz = accG[2] * dm;
+      const float sx = gx * c.pressure_sign, sy = gy * c.pressure_sign, sz = gz * c.pressure_sign;
+      fx += sx;
+      fy += sy;
+      fz += sz;
+    }
+    if constexpr (WANT_V) {
+      const float tx = accV[0] * c.mu, ty = accV[1] * c.mu, tz = accV[2] * c.mu;
+      fx += tx;
+      fy += ty;
+      fz += tz;
+    }
+    fx += c.ext[0];
+    fy += c.ext[1];
+    fz += c.ext[2];
+    px = pin.x[i];
+    py = pin.y[i];
+    pz = pin.z[i];
+    vx = vin.x[i];
+    vy = vin.y[i];
+    vz = vin.z[i];
+  }
+  integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats);
+  if (live) {
+    pout.x[i] = px;
+    pout.y[i] = py;
+    pout.z[i] = pz;
+    vout.x[i] = vx;
+    vout.y[i] = vy;
+    vout.z[i] = vz;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// PCISPH (solver/pcisph/pcisph_darwin.go:52-99)
+// ---------------------------------------------------------------------------------
+
+// predict :57-73 -- _vel += (F/m) dt ; _pos += _vel dt (state persists across steps)
+__global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, CSoa3 f, Soa3 pp, Soa3 pv,
+                                                        const DevStats* stats) {
+  if (stats->pci_done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= c.n) return;
+  const float ax = f.x[i] * c.inv_mass, ay = f.y[i] * c.inv_mass, az = f.z[i] * c.inv_mass;
+  const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
+  const float tvx = pv.x[i] + dvx, tvy = pv.y[i] + dvy, tvz = pv.z[i] + dvz;
+  const float dpx = tvx * c.dt, dpy = tvy * c.dt, dpz = tvz * c.dt;
+  pp.x[i] += dpx;
+  pp.y[i] += dpy;
+  pp.z[i] += dpz;
+  pv.x[i] = tvx;
+  pv.y[i] = tvy;
+  pv.z[i] = tvz;
+}
+
+// DF + pressure accumulate :76-92 -- SPHField.DensityF (sph_field.go:137-152): starts at
+// W0, includes self, neighbours' CURRENT positions around the PREDICTED position.
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+                                                        CSoa3 pp, float* __restrict__ press, DevStats* stats) {
+  if (stats->pci_done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  unsigned int err_bits = 0u;
+  if (i < c.n) {
+    const float xi = pp.x[i], yi = pp.y[i], zi = pp.z[i];
+    float density = c.W0;
+    for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+      const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+      const float r2 = dist2<FAST>(dx, dy, dz);
+      if constexpr (FAST) {
+        if (r2 < c.hh) {
+          const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+          density = __builtin_fmaf(c.mass * c.A, q * q, density);
+        }
+      } else {
+        const float dist = dsl_sqrt<false>(r2);
+        if (dist < c.h) {
+          const float w = kern_F<false>(c, dist);
+          density += c.mass * w;
+        }
+      }
+    });
+    const float density_error = density - c.ref_density;
+    const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
+    const float dp = density_error * c.delta;
+    press[i] += dp;
+    err_bits = nonneg_bits(abs_err);
+  }
+  wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
+}
+
+// end of one correction iteration :95-98
+__global__ void k_pci_check(DevConsts c, DevStats* stats) {
+  if (stats->pci_done) return;
+  const unsigned int e = stats->pci_cur_err_bits;
+  stats->pci_last_err_bits = e;
+  stats->pci_iters += 1;
+  stats->pci_cur_err_bits = 0u;
+  if (__uint_as_float(e) <= c.pci_max_error) stats->pci_done = 1;
+}
+__global__ void k_pci_reset(DevStats* stats) {
+  stats->pci_done = 0;
+  stats->pci_iters = 0;
+  stats->pci_cur_err_bits = 0u;
+  stats->pci_last_err_bits = 0u;
+}
+
+}  // namespace dsl

@@ -1,0 +1,178 @@
+// sph_device.hpp -- device-side constants, kernel functions and the neighbour sweep of
+// the gfx950 SPH engine.  Written for CDNA4 only (64-wide wavefronts); no portability
+// layer.  Reference citations are file:line inside the dieselfluid repository.
+//
+// Two arithmetic modes, selected at launch by template parameter:
+//   EXACT (FAST=false): one IEEE float32 rounding per reference operation, correctly
+//     rounded sqrt/divide, double pow -- the translation unit is compiled with
+//     -ffp-contract=off so nothing fuses implicitly.
+//   FAST  (FAST=true):  explicit fma, v_rcp_f32 / v_rsq_f32, float32 log1p/expm1 EOS.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsl {
+
+constexpr int kWave = 64;
+
+struct DevConsts {
+  int n;
+  // kernel/std_kernel.go:20-31
+  float h, hh, inv_h, inv_hh, A, B, C, W0;
+  float mass, inv_mass, ref_density, mu, dt, delta;
+  // model/model.go:92-101
+  float eos_wg, eos_gamma, eos_d0_grad;
+  float pressure_sign;
+  int visc_running_mass;
+  float reset[3], ext[3];
+  int wcsph_pressure_force, wcsph_viscosity;
+  float pci_max_error;
+  int walls;
+  float bmin[3], bmax[3], rest;
+  // uniform grid: cell edge = h, x-fastest linearisation
+  float gmin[3];
+  float inv_cell;
+  int dims[3];
+  int ncell;
+};
+
+// Host-visible counters living in device memory (fluid.go:25-26, pcisph_darwin.go:46-98).
+struct DevStats {
+  unsigned int max_vel_bits;  // non-negative float bit patterns order like unsigned ints
+  unsigned int max_f_bits;
+  unsigned int pci_cur_err_bits;   // running max of the current PCISPH iteration
+  unsigned int pci_last_err_bits;  // max_error_ratio of the last completed iteration
+  int pci_iters;
+  int pci_done;
+  int max_cell_count;
+  int pad;
+};
+
+// ---------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ float dsl_sqrt(float x) {
+  if constexpr (FAST) return __builtin_amdgcn_sqrtf(x);
+  else return __builtin_sqrtf(x);  // correctly rounded (-fhip-fp32-correctly-rounded-divide-sqrt)
+}
+template <bool FAST>
+__device__ __forceinline__ float dsl_div(float a, float b) {
+  if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
+  else return a / b;
+}
+
+// kernel/std_kernel.go:33-39  F(x) = x>=h ? 0 : A*q*q, q = 1 - x*x/(h*h)
+template <bool FAST>
+__device__ __forceinline__ float kern_F(const DevConsts& c, float dist) {
+  if (dist >= c.h) return 0.0f;
+  float xx = dist * dist;
+  float q;
+  if constexpr (FAST) q = __builtin_fmaf(-xx, c.inv_hh, 1.0f);
+  else q = 1.0f - xx / c.hh;
+  float aq = c.A * q;
+  return aq * q;
+}
+// kernel/std_kernel.go:54-60  O1D(x) = x>=h ? 0 : B*q*q, q = 1 - x/h
+template <bool FAST>
+__device__ __forceinline__ float kern_O1D(const DevConsts& c, float dist) {
+  if (dist >= c.h) return 0.0f;
+  float q;
+  if constexpr (FAST) q = __builtin_fmaf(-dist, c.inv_h, 1.0f);
+  else q = 1.0f - dist / c.h;
+  float bq = c.B * q;
+  return bq * q;
+}
+// kernel/std_kernel.go:63-71  O2D(x) = x>h ? 0 : C*q
+template <bool FAST>
+__device__ __forceinline__ float kern_O2D(const DevConsts& c, float dist) {
+  if (dist > c.h) return 0.0f;
+  float q;
+  if constexpr (FAST) q = __builtin_fmaf(-dist, c.inv_h, 1.0f);
+  else q = 1.0f - dist / c.h;
+  return c.C * q;
+}
+
+// model/model.go:92-101 TaitEos(x, d0, 0)
+template <bool FAST>
+__device__ __forceinline__ float tait_eos(const DevConsts& c, float x, float d0) {
+  if (x <= d0) x = d0;
+  float ratio = dsl_div<FAST>(x, d0);
+  float pw;
+  if constexpr (FAST) {
+    // (1+e)^g - 1 without the cancellation of powf(...)-1
+    pw = expm1f(c.eos_gamma * log1pf(ratio - 1.0f));
+  } else {
+    pw = (float)(pow((double)ratio, (double)c.eos_gamma) - 1.0);
+  }
+  float y = c.eos_wg * pw;
+  return y + 0.0f;
+}
+
+// Cell coordinate rule (DESIGN.md "grid"): floor((p-gmin)*inv_cell) clamped; NaN -> 0.
+__device__ __forceinline__ int cell_coord(float p, float gmin, float inv_cell, int dim) {
+  float f = floorf((p - gmin) * inv_cell);
+  if (!(f >= 0.0f)) return 0;
+  if (f >= (float)dim) return dim - 1;
+  return (int)f;
+}
+__device__ __forceinline__ int cell_of(const DevConsts& c, float x, float y, float z) {
+  int cx = cell_coord(x, c.gmin[0], c.inv_cell, c.dims[0]);
+  int cy = cell_coord(y, c.gmin[1], c.inv_cell, c.dims[1]);
+  int cz = cell_coord(z, c.gmin[2], c.inv_cell, c.dims[2]);
+  return (cz * c.dims[1] + cy) * c.dims[0] + cx;
+}
+
+// Candidate sweep: the 27 cells around (x,y,z) as 9 x-runs; thanks to the x-fastest
+// linearisation the three cells of a run are one contiguous slot range.  Order: z, y,
+// then slots ascending -- the same order the oracle's DSLO_ORDER_CELL uses.
+template <class Body>
+__device__ __forceinline__ void for_each_candidate(const DevConsts& c, const int* __restrict__ cell_start,
+                                                   float x, float y, float z, Body&& body) {
+  const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
+  const int cx = cell_coord(x, c.gmin[0], c.inv_cell, nx);
+  const int cy = cell_coord(y, c.gmin[1], c.inv_cell, ny);
+  const int cz = cell_coord(z, c.gmin[2], c.inv_cell, nz);
+  const int x0 = cx > 0 ? cx - 1 : 0;
+  const int x1 = cx < nx - 1 ? cx + 1 : nx - 1;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int zz = cz + dz;
+    if (zz < 0 || zz >= nz) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = cy + dy;
+      if (yy < 0 || yy >= ny) continue;
+      const int row = (zz * ny + yy) * nx;
+      const int jb = cell_start[row + x0];
+      const int je = cell_start[row + x1 + 1];
+      for (int j = jb; j < je; ++j) body(j);
+    }
+  }
+}
+
+// squared distance in the reference's rounding order (vector.go:301-308 Mag)
+template <bool FAST>
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) {
+  if constexpr (FAST) return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+  else {
+    float s = dx * dx;
+    float t = dy * dy;
+    s = s + t;
+    t = dz * dz;
+    return s + t;
+  }
+}
+
+// wave-level max of non-negative float bit patterns, one atomic per wave
+__device__ __forceinline__ void wave_atomic_max(unsigned int* addr, unsigned int v) {
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    unsigned int o = __shfl_xor(v, off, kWave);
+    v = o > v ? o : v;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && v != 0u) atomicMax(addr, v);
+}
+__device__ __forceinline__ unsigned int nonneg_bits(float v) {
+  return v > 0.0f ? __float_as_uint(v) : 0u;  // NaN and <=0 contribute nothing
+}
+
+}  // namespace dsl

@@ -1,0 +1,163 @@
+"""SPHEngine: thin object wrapper over the C ABI (include/dslsph.h).
+
+Method names follow model/sph.SPH (model/sph/fluid.go:111-215) and the solver drivers
+(solver/wcsph/wcsph.go, solver/pcisph/pcisph_darwin.go) so the parity tests read like
+the reference's call sequences.  Every method is one C-ABI call; no arithmetic happens
+in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import DslError, Params, Stats, load_library
+
+BUF = {
+    "positions": 0, "velocities": 1, "forces": 2, "densities": 3, "pressures": 4,
+    "pci_positions": 5, "pci_velocities": 6,
+}
+_COMPS = {0: 3, 1: 3, 2: 3, 3: 1, 4: 1, 5: 3, 6: 3}
+KERNEL_IDS = {
+    "cell_rank": 0, "scan": 1, "scatter": 2, "density": 3, "force_integrate": 4, "pressure": 5, "viscous": 6,
+    "gradient": 7, "external": 8, "update": 9, "pci_predict": 10, "pci_density": 11,
+}
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def reference_params(n3: int) -> Params:
+    """sph.Init's constants (dsl_params_reference)."""
+    L = load_library()
+    p = Params()
+    rc = L.dsl_params_reference(C.byref(p), int(n3))
+    if rc:
+        raise DslError(L.dsl_last_error(None).decode())
+    return p
+
+
+class SPHEngine:
+    def __init__(self, params: Params, device: int = 0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        rc = self._L.dsl_create(C.byref(params), int(device), C.byref(self._h))
+        if rc:
+            raise DslError(f"dsl_create failed ({rc}): {self._L.dsl_last_error(None).decode()}")
+        self.n = int(params.n_particles)
+        self.device = device
+
+    # -- plumbing -----------------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            raise DslError(f"libdslsph error {rc}: {self._L.dsl_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dsl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def params(self) -> Params:
+        p = Params()
+        self._ck(self._L.dsl_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_params(self, p: Params):
+        self._ck(self._L.dsl_set_params(self._h, C.byref(p)))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self._L.dsl_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # -- buffers (ComputeGPU.PassFloatBuffer / ReadFloatBuffer) -------------------
+    def upload(self, name: str, arr):
+        b = BUF[name]
+        a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        self._ck(self._L.dsl_upload(self._h, b, _fp(a), a.size))
+
+    def download(self, name: str, sorted_order: bool = False) -> np.ndarray:
+        b = BUF[name]
+        out = np.empty(self.n * _COMPS[b], dtype=np.float32)
+        fn = self._L.dsl_download_sorted if sorted_order else self._L.dsl_download
+        self._ck(fn(self._h, b, _fp(out), out.size))
+        return out.reshape(self.n, 3) if _COMPS[b] == 3 else out
+
+    def download_ids(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.int32)
+        self._ck(self._L.dsl_download_ids(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size))
+        return out
+
+    def download_cell_start(self) -> np.ndarray:
+        cells = self.stats().grid_cells
+        out = np.empty(cells + 1, dtype=np.int32)
+        self._ck(self._L.dsl_download_cell_start(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size))
+        return out
+
+    # -- model/sph.SPH passes -----------------------------------------------------
+    def nn(self):
+        self._ck(self._L.dsl_build_neighbours(self._h))
+
+    def density_all(self):
+        self._ck(self._L.dsl_density_pass(self._h))
+
+    def pressure_all(self):
+        self._ck(self._L.dsl_pressure_pass(self._h))
+
+    def viscous_all(self):
+        self._ck(self._L.dsl_viscous_pass(self._h))
+
+    def external_all(self, f):
+        a = np.ascontiguousarray(f, dtype=np.float32)
+        self._ck(self._L.dsl_external_pass(self._h, _fp(a)))
+
+    def gradient_pressure_force(self):
+        self._ck(self._L.dsl_gradient_pressure_pass(self._h))
+
+    def update(self):
+        self._ck(self._L.dsl_update_pass(self._h))
+
+    def force_pass(self):
+        self._ck(self._L.dsl_force_pass(self._h))
+
+    # -- solver drivers -----------------------------------------------------------
+    def wcsph_step(self, nsteps: int = 1):
+        self._ck(self._L.dsl_wcsph_step(self._h, int(nsteps)))
+
+    def pcisph_begin(self):
+        self._ck(self._L.dsl_pcisph_begin(self._h))
+
+    def pcisph_step(self, nsteps: int = 1):
+        self._ck(self._L.dsl_pcisph_step(self._h, int(nsteps)))
+
+    def sync(self):
+        self._ck(self._L.dsl_sync(self._h))
+
+    def stats(self) -> Stats:
+        s = Stats()
+        self._ck(self._L.dsl_get_stats(self._h, C.byref(s)))
+        return s
+
+    # -- timing ---------------------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        self._ck(self._L.dsl_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        self._ck(self._L.dsl_timing_reset(self._h))
+
+    def timing(self, kernel: str):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self._ck(self._L.dsl_timing_get(self._h, KERNEL_IDS[kernel], C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value

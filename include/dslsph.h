@@ -1,0 +1,202 @@
+/*
+ * dslsph.h -- C ABI of libdslsph.so, the MI355X (gfx950) SPH particle-step engine that
+ * sits where dieselfluid's OpenCL path sits (compute/gpu + solver/pcisph GPU driver).
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status codes.  No torch types,
+ * no C++ types.  Bound from Go through cgo (bindings/go/dslsph), from C++ through
+ * dieselfluid_amd/host/dieselfluid.hpp and from Python through ctypes
+ * (dieselfluid_amd/_lib.py).  See INTEGRATION.md for the reference-side stubs.
+ *
+ * Every entry point cites the reference interface it replaces
+ * (file:line relative to the dieselfluid repository root).
+ *
+ * Threading: a handle is single-owner (not thread-safe); every call re-selects the
+ * handle's device first because goroutines migrate between OS threads.  Host pointers
+ * are never retained after a call returns (cgo pointer rule).
+ */
+#ifndef DSLSPH_H
+#define DSLSPH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSL_ABI_VERSION 1
+
+/* status codes: 0 = ok; negative = error, text from dsl_last_error() */
+enum {
+  DSL_OK = 0,
+  DSL_ERR_INVALID = -1,  /* bad argument / bad state            */
+  DSL_ERR_DEVICE = -2,   /* HIP runtime error                   */
+  DSL_ERR_NOMEM = -3,    /* host or device allocation failure   */
+  DSL_ERR_UNSUPPORTED = -4
+};
+
+/* Named device buffers; the names are the ones the reference registers in
+ * solver/pcisph/pcisph_gpu_darwin.go:67-76 ("positions", "velocities", "forces",
+ * "densities", "pressures", "temps").  Host layout is the reference's: xyz interleaved
+ * float32 (model/particle_array.go:5-15); the library converts to SoA on device. */
+enum {
+  DSL_BUF_POSITIONS = 0,  /* N*3 floats */
+  DSL_BUF_VELOCITIES = 1, /* N*3 floats */
+  DSL_BUF_FORCES = 2,     /* N*3 floats */
+  DSL_BUF_DENSITIES = 3,  /* N floats   */
+  DSL_BUF_PRESSURES = 4,  /* N floats   */
+  DSL_BUF_PCI_POSITIONS = 5,  /* "temps".pos, N*3: predictor state of pcisph_darwin.go:28-41 */
+  DSL_BUF_PCI_VELOCITIES = 6, /* "temps".vel, N*3 */
+  DSL_BUF_COUNT = 7
+};
+
+enum {
+  DSL_NEIGH_GRID = 1 /* all j with |xi-xj| < h via uniform-grid counting sort */
+};
+enum {
+  DSL_MATH_EXACT = 0, /* IEEE float32, one rounding per reference operation, f64 pow */
+  DSL_MATH_FAST = 1   /* fused multiply-add, hardware rcp/rsq, float32 pow          */
+};
+
+/* Parameter block.  The first nine fields are the reference's "sizes" and "floats"
+ * blocks (pcisph_gpu_darwin.go:60-61); the rest are the reference's compile-time
+ * constants made explicit.  dsl_params_reference() fills in the reference's values. */
+typedef struct dsl_params {
+  uint32_t struct_size; /* = sizeof(dsl_params); ABI check */
+  uint32_t abi_version; /* = DSL_ABI_VERSION               */
+  /* "sizes" */
+  int32_t n_particles;     /* field.Particles.N()                   */
+  int32_t n_boundary;      /* Total()-N(); must be 0 (fluid.go:70)  */
+  int32_t lsh_buckets;     /* carried for the Go side; unused here  */
+  int32_t lsh_bucket_size; /* carried for the Go side; unused here  */
+  /* "floats" */
+  float dt;      /* SPH.CFL()   model/sph/fluid.go:111-114 (0.01) */
+  float mass;    /* field.Mass()                         (1.0)    */
+  float delta;   /* SPH.Delta() fluid.go:204,221-273              */
+  float max_vel; /* SPH.MaxV()  initial value                     */
+  float h;       /* kernel length fluid.go:48            (1.0)    */
+  /* constants of the reference */
+  float ref_density; /* ParticleArray.D0() particle_array.go:26 (N/8)  */
+  float mu;          /* VISCOSITY_WATER fluid.go:18 (1.3059)           */
+  float eos_w;       /* model/model.go:94 (2.15)                       */
+  float eos_gamma;   /* model/model.go:93 (7.16)                       */
+  float eos_d0_grad; /* FLUID_DENSITY, field_types.go:41 (87.0)        */
+  float pressure_sign;       /* +1: fluid.go:168-169 adds the gradient  */
+  int32_t visc_running_mass; /* 1: sph_field.go:265 running-sum * m     */
+  float force_reset[3];      /* fluid.go:193 (0,-9.81*m,0)              */
+  float external[3];         /* wcsph.go:19  (0,-9.81,0)                */
+  int32_t wcsph_pressure_force; /* 0: absent from wcsph.go:14-26        */
+  int32_t wcsph_viscosity;      /* 0: absent from wcsph.go:14-26        */
+  int32_t pci_max_iters;        /* pcisph_darwin.go:49 (5)              */
+  float pci_max_error;          /* pcisph_darwin.go:50 (0.01)           */
+  /* build-defined: axis-aligned wall box applied at the end of Update */
+  int32_t walls;
+  float box_min[3], box_max[3];
+  float restitution;
+  /* uniform grid for the neighbour table; cell edge = h */
+  float grid_min[3], grid_max[3];
+  int32_t neigh_mode; /* DSL_NEIGH_GRID */
+  int32_t math_mode;  /* DSL_MATH_*     */
+  int32_t reserved[8];
+} dsl_params;
+
+/* Counters the reference keeps on the host (fluid.go:25-26,186-191) plus the PCISPH loop
+ * outcome (pcisph_darwin.go:46-98). */
+typedef struct dsl_stats {
+  float max_vel, max_f;
+  float pci_max_error;
+  int32_t pci_iters;
+  int64_t steps;
+  int32_t grid_dims[3];
+  int32_t grid_cells;
+  int32_t max_cell_count; /* most crowded cell at the last neighbour build */
+} dsl_stats;
+
+/* kernel ids for dsl_timing_get */
+enum {
+  DSL_K_CELL_RANK = 0,
+  DSL_K_SCAN = 1,
+  DSL_K_SCATTER = 2,
+  DSL_K_DENSITY = 3,
+  DSL_K_FORCE_INTEGRATE = 4, /* fused WCSPH pressure+viscosity+external+Update */
+  DSL_K_PRESSURE = 5,
+  DSL_K_VISCOUS = 6,
+  DSL_K_GRADIENT = 7,
+  DSL_K_EXTERNAL = 8,
+  DSL_K_UPDATE = 9,
+  DSL_K_PCI_PREDICT = 10,
+  DSL_K_PCI_DENSITY = 11,
+  DSL_K_COUNT = 12
+};
+
+typedef struct dsl_handle dsl_handle;
+
+/* sph.Init's constants for an n3^3 system (model/sph/fluid.go:41-88). */
+int dsl_params_reference(dsl_params *out, int n3);
+
+/* gpu.InitOpenCL + gpu.New_ComputeGPU + New_GPUPredictorCorrector's ten RegisterBuffer
+ * calls (compute/gpu/gpu.go:45-119,314; pcisph_gpu_darwin.go:36-76).  `device` is the
+ * HIP device ordinal. */
+int dsl_create(const dsl_params *params, int device, dsl_handle **out);
+int dsl_destroy(dsl_handle *h);
+
+/* Scalars may change between steps (dt, delta, mu, ...); n_particles and the grid box
+ * may not. */
+int dsl_set_params(dsl_handle *h, const dsl_params *params);
+int dsl_get_params(dsl_handle *h, dsl_params *out);
+
+/* ComputeGPU.PassFloatBuffer / ReadFloatBuffer (compute/gpu/gpu.go:343-352,332-341) and
+ * the per-step EnqueueReadBufferFloat32 of pcisph_gpu_darwin.go:276-277.  Blocking;
+ * `count` is the number of floats and must match the buffer. */
+int dsl_upload(dsl_handle *h, int buffer, const float *host, size_t count);
+int dsl_download(dsl_handle *h, int buffer, float *host, size_t count);
+
+/* SPH.NN() / HashSampler.UpdateSampler (fluid.go:100-102, sampler/lsh/lsh.go:126-133):
+ * rebuilds the neighbour table (cell hash, histogram, prefix sum, counting-sort scatter). */
+int dsl_build_neighbours(dsl_handle *h);
+
+/* The whole-array passes of model/sph/fluid.go, one to one. */
+int dsl_density_pass(dsl_handle *h);                  /* DensityAll            :127-131 */
+int dsl_pressure_pass(dsl_handle *h);                 /* PressureAll           :134-142 */
+int dsl_viscous_pass(dsl_handle *h);                  /* ViscousAll            :146-152 */
+int dsl_external_pass(dsl_handle *h, const float f[3]); /* ExternalAll         :155-161 */
+int dsl_gradient_pressure_pass(dsl_handle *h);        /* GradientPressureForce :164-172 */
+int dsl_update_pass(dsl_handle *h);                   /* Update                :175-197 */
+/* Fused form of [GradientPressureForce][ViscousAll] ExternalAll PressureAll Update used by
+ * dsl_wcsph_step; needs densities from dsl_density_pass. */
+int dsl_force_pass(dsl_handle *h);
+
+/* Step drivers: one iteration of WCSPH.Run (solver/wcsph/wcsph.go:14-26) and of
+ * PciMethod.Run (solver/pcisph/pcisph_darwin.go:43-101) per step.  Asynchronous: they
+ * return once the work is queued; dsl_sync/dsl_download/dsl_get_stats wait. */
+int dsl_wcsph_step(dsl_handle *h, int nsteps);
+int dsl_pcisph_begin(dsl_handle *h); /* pcisph_darwin.go:28-41 predictor copies */
+int dsl_pcisph_step(dsl_handle *h, int nsteps);
+
+int dsl_get_stats(dsl_handle *h, dsl_stats *out);
+int dsl_sync(dsl_handle *h); /* Queue.Finish() pcisph_gpu_darwin.go:261,271 */
+
+/* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL
+ * restores the handle's own stream. */
+int dsl_set_stream(dsl_handle *h, void *hip_stream);
+
+/* Per-kernel device timing with HIP events recorded on the launch stream. */
+int dsl_timing_enable(dsl_handle *h, int on);
+int dsl_timing_reset(dsl_handle *h);
+int dsl_timing_get(dsl_handle *h, int kernel_id, double *avg_ms, int64_t *launches);
+
+/* Debug/parity aid: state in the device's current (cell-sorted) order.
+ * ids[s] is the original particle index held by slot s. */
+int dsl_download_sorted(dsl_handle *h, int buffer, float *host, size_t count);
+int dsl_download_ids(dsl_handle *h, int32_t *ids, size_t count);
+int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
+
+/* Error text of the last failing call on this handle (NULL handle: creation errors).
+ * Replaces log.Fatalf in compute/gpu/gpu.go:52,66,234,339: the process is never aborted. */
+const char *dsl_last_error(dsl_handle *h);
+const char *dsl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,204 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on identical
+seeded inputs.  EXACT math mode is held to near-bit agreement (differences come only
+from the summation order inside a cell, which the atomic counting sort leaves free);
+FAST mode to the float32 tolerances written next to each check."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+EXACT, FAST = 0, 1
+
+
+def _engine(p):
+    from dieselfluid_amd import SPHEngine
+    return SPHEngine(p, device=0)
+
+
+def _reference_system(n3, math_mode, amp=0.2, vel_scale=0.1):
+    """Reference constants (h=1, m=1, rho0=N/8, mu=1.3059, dt=0.01) on the jittered
+    [-1,1)^3 lattice of SURVEY 8c fixture (2), grid neighbours."""
+    from dieselfluid_amd import scenes
+    p, _ = scenes.reference_scene(n3)
+    p.math_mode = math_mode
+    pos = helpers.jittered_lattice(n3, amp)
+    vel = helpers.seeded_velocities(n3 ** 3, vel_scale)
+    return p, pos, vel
+
+
+@pytest.mark.parametrize("math_mode,tol", [(EXACT, 2e-6), (FAST, 2e-5)])
+def test_density_pass(math_mode, tol):
+    """D: SPHField.Density (sph_field.go:155-172)."""
+    p, pos, vel = _reference_system(12, math_mode)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.density_all()
+    rho = eng.download("densities")
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos)
+    ora.density_all()
+    assert helpers.rel_err(rho, ora.densities()) < tol
+
+
+def test_density_bit_exact_in_device_order():
+    """With the oracle fed the particles in the device's sorted slot order (so both sum
+    each cell in the same order) EXACT mode must agree bit for bit."""
+    p, pos, vel = _reference_system(12, EXACT)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.density_all()
+    spos = eng.download("positions", sorted_order=True)
+    srho = eng.download("densities", sorted_order=True)
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), spos)
+    ora.density_all()
+    assert np.array_equal(srho.view(np.uint32), ora.densities().view(np.uint32))
+
+
+def test_sort_is_a_permutation_and_sorted():
+    """N: counting sort -- ids are a permutation, cell ids ascend, cell_start matches."""
+    p, pos, vel = _reference_system(12, EXACT)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.nn()
+    ids = eng.download_ids()
+    assert np.array_equal(np.sort(ids), np.arange(eng.n))
+    spos = eng.download("positions", sorted_order=True)
+    assert np.array_equal(spos, pos[ids])
+    st = eng.stats()
+    dims = np.array(st.grid_dims[:])
+    inv = np.float32(1.0) / np.float32(p.h)
+    gmin = np.array(p.grid_min[:], dtype=np.float32)
+    c = np.floor((spos - gmin) * inv).astype(np.int64)
+    c = np.clip(c, 0, dims - 1)
+    cell = (c[:, 2] * dims[1] + c[:, 1]) * dims[0] + c[:, 0]
+    assert np.all(np.diff(cell) >= 0)
+    cs = eng.download_cell_start()
+    assert cs[0] == 0 and cs[-1] == eng.n
+    counts = np.bincount(cell, minlength=st.grid_cells)
+    assert np.array_equal(np.diff(cs), counts)
+    assert st.max_cell_count == counts.max()
+
+
+@pytest.mark.parametrize("math_mode,tol", [(EXACT, 5e-6), (FAST, 5e-5)])
+def test_reference_pass_sequence(math_mode, tol):
+    """The passes of sph.Init and one PCISPH-style force build-up, one C-ABI call per
+    reference method: DensityAll, ExternalAll, ViscousAll, GradientPressureForce,
+    PressureAll, Update (fluid.go:127-197)."""
+    p, pos, vel = _reference_system(12, math_mode)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("velocities", vel)
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel)
+    g = np.array([0, -9.81, 0], dtype=np.float32)
+    eng.density_all(); ora.density_all()
+    eng.external_all(g); ora.external_all(g)
+    eng.viscous_all(); ora.viscous_all()
+    f1 = eng.download("forces")
+    assert helpers.rel_err(f1, ora.forces()) < tol
+    eng.gradient_pressure_force(); ora.gradient_pressure_force()
+    f2 = eng.download("forces")
+    assert helpers.rel_err(f2, ora.forces()) < tol
+    eng.pressure_all(); ora.pressure_all()
+    assert helpers.rel_err(eng.download("pressures"), ora.pressures()) < tol
+    eng.update(); ora.update()
+    assert helpers.rel_err(eng.download("positions"), ora.positions()) < tol
+    assert helpers.rel_err(eng.download("velocities"), ora.velocities()) < tol
+    # Update resets force and pressure (fluid.go:192-193)
+    assert np.array_equal(eng.download("forces"), ora.forces())
+    assert np.array_equal(eng.download("pressures"), ora.pressures())
+    st = eng.stats()
+    assert abs(st.max_vel - ora.max_vel) <= tol * ora.max_vel
+    assert abs(st.max_f - ora.max_f) <= tol * ora.max_f
+
+
+def test_wcsph_free_fall_known_answer():
+    """W: the reference WCSPH loop has no pressure force and double gravity: after steps
+    1,2,3 v_y = -0.1962,-0.3924,-0.5886 and y(-1) = -1.001962,-1.005886,-1.0117719
+    (SURVEY 8c).  Bit-exact in EXACT mode."""
+    from dieselfluid_amd import scenes
+    p, pos = scenes.reference_scene(8)
+    p.math_mode = EXACT
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    frc = np.tile(np.array([0, -9.81, 0], dtype=np.float32), (eng.n, 1))
+    eng.upload("forces", frc)  # state after sph.Init: gravity (viscous term is 0 at rest)
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, force=frc)
+    want_v = [np.float32(-0.1962), np.float32(-0.3924), np.float32(-0.5886)]
+    want_y = [np.float32(-1.001962), np.float32(-1.005886), np.float32(-1.0117719)]
+    for k in range(3):
+        eng.wcsph_step(1); ora.wcsph_step(1)
+        v = eng.download("velocities"); x = eng.download("positions")
+        assert np.array_equal(v, ora.velocities())
+        assert np.array_equal(x, ora.positions())
+        assert v[0, 1] == want_v[k] and x[0, 1] == want_y[k]
+
+
+@pytest.mark.parametrize("math_mode,tol_x,tol_v", [(EXACT, 1e-6, 1e-4), (FAST, 1e-5, 1e-3)])
+def test_wcsph_dambreak_10_steps(math_mode, tol_x, tol_v):
+    """Build-defined dam-break (pressure + viscosity + walls) through the fused
+    force+integrate kernel, 10 steps, against the oracle's pass-by-pass loop."""
+    from dieselfluid_amd import scenes
+    n3 = 16
+    p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+    frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (n3 ** 3, 1))
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("forces", frc)
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, force=frc)
+    eng.wcsph_step(10); ora.wcsph_step(10)
+    assert helpers.rel_err(eng.download("positions"), ora.positions()) < tol_x
+    assert helpers.rel_err(eng.download("velocities"), ora.velocities(), floor=1e-2) < tol_v
+    assert helpers.rel_err(eng.download("densities"), ora.densities()) < 10 * tol_x
+
+
+@pytest.mark.parametrize("math_mode,tol", [(EXACT, 2e-5), (FAST, 2e-4)])
+def test_pcisph_steps(math_mode, tol):
+    """PC: PciMethod.Run (pcisph_darwin.go:43-101), 2 steps with 5 and 4 max iterations."""
+    p, pos, vel = _reference_system(12, math_mode, amp=0.1, vel_scale=0.05)
+    for iters in (5, 4):
+        p.pci_max_iters = iters
+        p.delta = 1.0e-4
+        eng = _engine(p)
+        eng.upload("positions", pos)
+        eng.upload("velocities", vel)
+        ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel)
+        ora.delta = p.delta
+        eng.pcisph_begin(); ora.pcisph_begin()
+        for step in range(2):
+            eng.pcisph_step(1); ora.pcisph_step(1)
+            st = eng.stats()
+            assert st.pci_iters == ora.pci_iters
+            assert abs(st.pci_max_error - ora.pci_error) <= tol * max(abs(ora.pci_error), 1e-3)
+            assert helpers.rel_err(eng.download("positions"), ora.positions()) < tol
+            assert helpers.rel_err(eng.download("velocities"), ora.velocities()) < tol
+            assert helpers.rel_err(eng.download("pci_positions"), ora.pci_positions()) < tol
+            assert helpers.rel_err(eng.download("pci_velocities"), ora.pci_velocities()) < tol
+        eng.close()
+
+
+def test_upload_download_roundtrip_after_sort():
+    """P: buffers keep the reference's host order across the device's re-sorting."""
+    p, pos, vel = _reference_system(8, EXACT)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("velocities", vel)
+    eng.nn()
+    assert np.array_equal(eng.download("positions"), pos)
+    assert np.array_equal(eng.download("velocities"), vel)
+    vel2 = (vel * np.float32(2)).astype(np.float32)
+    eng.upload("velocities", vel2)  # upload while the device order is permuted
+    assert np.array_equal(eng.download("velocities"), vel2)
+
+
+def test_error_paths_do_not_abort():
+    from dieselfluid_amd import SPHEngine, DslError, scenes
+    p, pos = scenes.reference_scene(4)
+    p.n_boundary = 3
+    with pytest.raises(DslError):
+        SPHEngine(p)
+    p.n_boundary = 0
+    eng = SPHEngine(p)
+    with pytest.raises(DslError):
+        eng.upload("positions", pos[:-1])
