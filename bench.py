@@ -103,7 +103,7 @@ def main():
         from dieselfluid_amd import slab
         drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank)
         step = drv.wcsph_step
-        engines = [drv.engine]
+        engines = [drv.engine_core]
 
     def barrier():
         if world > 1:

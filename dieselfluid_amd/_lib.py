@@ -35,8 +35,8 @@ class Params(C.Structure):
         ("pci_max_iters", C.c_int32), ("pci_max_error", C.c_float),
         ("walls", C.c_int32), ("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("restitution", C.c_float),
         ("grid_min", C.c_float * 3), ("grid_max", C.c_float * 3),
-        ("neigh_mode", C.c_int32), ("math_mode", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("neigh_mode", C.c_int32), ("math_mode", C.c_int32), ("capacity", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 
@@ -78,6 +78,12 @@ EXPORTS = {
     "dsl_download_sorted": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
     "dsl_download_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_download_cell_start": (C.c_int, [_vp, _ip, C.c_size_t]),
+    "dsl_slab_config": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float]),
+    "dsl_slab_pack": (C.c_int, [_vp, C.c_int, C.c_float, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "dsl_slab_append": (C.c_int, [_vp, _vp, C.c_int]),
+    "dsl_get_count": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dsl_set_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
+    "dsl_reset_forces": (C.c_int, [_vp]),
     "dsl_last_error": (C.c_char_p, [_vp]),
     "dsl_version": (C.c_char_p, []),
 }

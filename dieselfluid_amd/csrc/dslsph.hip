@@ -37,7 +37,9 @@ struct dsl_handle {
   hipStream_t own_stream = nullptr, stream = nullptr;
   dsl_params prm{};
   DevConsts c{};
-  int n = 0, ncell = 0, ncell_pad = 0, nscan = 0;
+  int n = 0, cap = 0, ncell = 0, ncell_pad = 0, nscan = 0;
+  bool ids_global = false;  // dsl_set_ids replaced the host-order map
+  int* dcounter = nullptr;
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -139,6 +141,10 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   }
   if (ncell > (1ll << 30)) return fail(h, DSL_ERR_INVALID, "grid has more than 2^30 cells; shrink the grid box or enlarge h");
   c.ncell = (int)ncell;
+  if (p.capacity != 0 && p.capacity < p.n_particles) return fail(h, DSL_ERR_INVALID, "capacity must be >= n_particles");
+  c.slab_axis = -1;
+  c.slab_lo = -INFINITY;
+  c.slab_hi = INFINITY;
   return DSL_OK;
 }
 
@@ -290,6 +296,14 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (!h->forces_uniform) h->cur_f ^= 1;
   if (h->pci_active) h->cur_pci ^= 1;
   h->grid_valid = true;
+  if (h->c.slab_axis >= 0) {
+    // departed particles and stale ghosts were sorted into the extra bucket `ncell`
+    int live = 0;
+    HIP_TRY(h, hipMemcpyAsync(&live, h->cell_start + h->ncell, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n = live;
+    h->c.n = live;
+  }
   return DSL_OK;
 }
 
@@ -425,6 +439,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->block_sums);
   (void)hipFree(h->stage);
   (void)hipFree(h->dstats);
+  (void)hipFree(h->dcounter);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (auto& v : h->pending)
     for (auto& pr : v) {
@@ -438,7 +453,7 @@ int alloc_pci(dsl_handle* h) {
   if (h->pci[0][0]) return DSL_OK;
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 6; ++k)
-      if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->n)) return rc;
+      if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
   return DSL_OK;
 }
 
@@ -510,10 +525,11 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     return rc;
   }
   h->n = h->c.n;
+  h->cap = params->capacity > 0 ? params->capacity : h->n;
   h->ncell = h->c.ncell;
   h->ncell_pad = ((h->ncell + 1 + kScanTile - 1) / kScanTile) * kScanTile;
   h->nscan = h->ncell_pad / kScanTile;
-  const size_t n = (size_t)h->n;
+  const size_t n = (size_t)h->cap;
   auto bail = [&](int code) {
     g_create_error = h->err;
     free_all(h);
@@ -537,7 +553,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
-      (rc = dev_alloc(h, &h->dstats, 1)))
+      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)))
     return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
@@ -551,7 +567,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     h->err = std::string("hipMemsetAsync: ") + hipGetErrorString(me);
     return bail(DSL_ERR_DEVICE);
   }
-  hipLaunchKernelGGL(k_iota, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->n, h->ids[0]);
+  hipLaunchKernelGGL(k_iota, dim3(grid_for(h->cap)), dim3(kBlock), 0, h->stream, h->cap, h->ids[0]);
   DevStats init{};
   init.max_vel_bits = params->max_vel > 0.f ? *reinterpret_cast<const unsigned int*>(&params->max_vel) : 0u;
   if (hipMemcpyAsync(h->dstats, &init, sizeof(init), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -580,9 +596,13 @@ int dsl_set_params(dsl_handle* h, const dsl_params* p) {
     return fail(h, DSL_ERR_INVALID, "dsl_set_params: dsl_params size/version mismatch");
   DevConsts c{};
   if (int rc = make_consts(h, *p, c)) return rc;
-  if (c.n != h->c.n || c.ncell != h->c.ncell || c.dims[0] != h->c.dims[0] || c.dims[1] != h->c.dims[1] ||
-      c.dims[2] != h->c.dims[2] || c.h != h->c.h)
-    return fail(h, DSL_ERR_INVALID, "dsl_set_params: n_particles, h and the grid box are fixed at creation");
+  if (p->n_particles != h->prm.n_particles || p->capacity != h->prm.capacity || c.ncell != h->c.ncell ||
+      c.dims[0] != h->c.dims[0] || c.dims[1] != h->c.dims[1] || c.dims[2] != h->c.dims[2] || c.h != h->c.h)
+    return fail(h, DSL_ERR_INVALID, "dsl_set_params: n_particles, capacity, h and the grid box are fixed at creation");
+  c.n = h->c.n;  // live count (slab mode changes it)
+  c.slab_axis = h->c.slab_axis;
+  c.slab_lo = h->c.slab_lo;
+  c.slab_hi = h->c.slab_hi;
   if (std::memcmp(c.reset, h->c.reset, sizeof(c.reset)) != 0 && h->forces_uniform) {
     if (int rc = materialise_forces(h)) return rc;  // keep the old implicit value
   }
@@ -611,6 +631,7 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_upload: bad buffer id or null pointer");
   const size_t n = (size_t)h->n;
   if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_upload: count does not match the buffer size");
+  if (h->ids_global) return fail(h, DSL_ERR_INVALID, "dsl_upload: host order is gone after dsl_set_ids");
   HIP_TRY(h, hipMemcpyAsync(h->stage, host, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
   const int* ids = h->ids[h->cur_ids];
   dim3 g(grid_for(h->n)), b(kBlock);
@@ -670,6 +691,8 @@ static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, i
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_download: bad buffer id or null pointer");
   const size_t n = (size_t)h->n;
   if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_download: count does not match the buffer size");
+  if (h->ids_global && !sorted_order)
+    return fail(h, DSL_ERR_INVALID, "dsl_download: host order is gone after dsl_set_ids; use dsl_download_sorted + dsl_download_ids");
   const int* ids = h->ids[h->cur_ids];
   dim3 g(grid_for(h->n)), b(kBlock);
   switch (buffer) {
@@ -850,6 +873,97 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
     if (int rc = update_pass(h)) return rc;         // Update :101
     h->steps++;
   }
+  return DSL_OK;
+}
+
+int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
+  CHECK_HANDLE(h);
+  if (axis < -1 || axis > 2 || !(lo < hi)) return fail(h, DSL_ERR_INVALID, "dsl_slab_config: bad axis or empty range");
+  if (h->pci_active) return fail(h, DSL_ERR_UNSUPPORTED, "slabs are implemented for the WCSPH step only");
+  h->c.slab_axis = axis;
+  h->c.slab_lo = axis < 0 ? -INFINITY : lo;
+  h->c.slab_hi = axis < 0 ? INFINITY : hi;
+  h->grid_valid = false;
+  return DSL_OK;
+}
+
+int dsl_slab_pack(dsl_handle* h, int side, float width, float* dev_records, int capacity, int* count) {
+  CHECK_HANDLE(h);
+  if (h->c.slab_axis < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: no slab configured");
+  if (!dev_records || !count || capacity < 0 || (side != 0 && side != 1) || !(width >= 0.0f))
+    return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: bad argument");
+  const float bound = side == 0 ? h->c.slab_lo + width : h->c.slab_hi - width;
+  HIP_TRY(h, hipMemsetAsync(h->dcounter, 0, sizeof(int), h->stream));
+  CSoa3 p = cpos(h), v = cvel(h);
+  if (h->n > 0) {
+    hipLaunchKernelGGL(k_slab_pack, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->c, side, bound, p.x, p.y, p.z,
+                       v.x, v.y, v.z, h->ids[h->cur_ids], dev_records, capacity, h->dcounter);
+    HIP_TRY(h, hipGetLastError());
+  }
+  int cnt = 0;
+  HIP_TRY(h, hipMemcpyAsync(&cnt, h->dcounter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  *count = cnt;
+  if (cnt > capacity) return fail(h, DSL_ERR_NOMEM, "dsl_slab_pack: band does not fit the record buffer");
+  return DSL_OK;
+}
+
+int dsl_slab_append(dsl_handle* h, const float* dev_records, int count) {
+  CHECK_HANDLE(h);
+  if (h->c.slab_axis < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: no slab configured");
+  if (count < 0 || (count > 0 && !dev_records)) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
+  if (!h->forces_uniform) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: forces must be uniform (dsl_reset_forces)");
+  if (h->n + count > h->cap) return fail(h, DSL_ERR_NOMEM, "dsl_slab_append: capacity exceeded");
+  if (count == 0) return DSL_OK;
+  Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
+  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(count)), dim3(kBlock), 0, h->stream, count, h->n, dev_records, p.x,
+                     p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids]);
+  HIP_TRY(h, hipGetLastError());
+  h->n += count;
+  h->c.n = h->n;
+  h->grid_valid = false;
+  h->dens_fresh = false;
+  return DSL_OK;
+}
+
+int dsl_get_count(dsl_handle* h, int* n_live, int* n_owned) {
+  CHECK_HANDLE(h);
+  if (n_live) *n_live = h->n;
+  if (n_owned) {
+    *n_owned = h->n;
+    if (h->c.slab_axis >= 0 && h->n > 0) {
+      HIP_TRY(h, hipMemsetAsync(h->dcounter, 0, sizeof(int), h->stream));
+      CSoa3 p = cpos(h);
+      hipLaunchKernelGGL(k_count_owned, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->c, p.x, p.y, p.z,
+                         h->dcounter);
+      HIP_TRY(h, hipGetLastError());
+      HIP_TRY(h, hipMemcpyAsync(n_owned, h->dcounter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  return DSL_OK;
+}
+
+int dsl_set_ids(dsl_handle* h, const int32_t* ids, size_t count) {
+  CHECK_HANDLE(h);
+  if (!ids || count != (size_t)h->n) return fail(h, DSL_ERR_INVALID, "dsl_set_ids: count must equal the particle count");
+  // ids follow the host order of dsl_upload: slot s currently holds host index cur_ids[s]
+  std::vector<int> cur(count), out(count);
+  HIP_TRY(h, hipMemcpyAsync(cur.data(), h->ids[h->cur_ids], count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (size_t s = 0; s < count; ++s) {
+    if (cur[s] < 0 || (size_t)cur[s] >= count) return fail(h, DSL_ERR_INVALID, "dsl_set_ids: ids were already replaced");
+    out[s] = ids[cur[s]];
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->ids[h->cur_ids], out.data(), count * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->ids_global = true;
+  return DSL_OK;
+}
+
+int dsl_reset_forces(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  h->forces_uniform = true;
   return DSL_OK;
 }
 

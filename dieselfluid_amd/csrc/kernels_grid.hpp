@@ -19,6 +19,10 @@ constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lan
 // same cell (the input is the previous step's sorted order), so equal-cell runs are
 // found with one ballot and only the run's first lane issues the atomic.
 // ---------------------------------------------------------------------------------
+// Slab mode: stale ghosts carry NaN positions (written by the integrate kernels); they go
+// to the extra bucket `ncell` and so sort behind every live particle.  A particle that has
+// just crossed the slab plane stays finite: it serves as a ghost for one more step, because
+// the neighbour packed its own band before receiving it.
 __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* __restrict__ px,
                                                       const float* __restrict__ py,
                                                       const float* __restrict__ pz, int* __restrict__ cellid,
@@ -26,7 +30,14 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   int cell = -1;
-  if (i < c.n) cell = cell_of(c, px[i], py[i], pz[i]);
+  if (i < c.n) {
+    const float x = px[i], y = py[i], z = pz[i];
+    cell = cell_of(c, x, y, z);
+    if (c.slab_axis >= 0) {
+      const bool finite = (x == x) && (y == y) && (z == z);
+      if (!finite) cell = c.ncell;
+    }
+  }
   const int prev = __shfl_up(cell, 1, kWave);
   const bool head = (lane == 0) || (cell != prev);
   const unsigned long long heads = __ballot(head);
@@ -193,6 +204,77 @@ __global__ __launch_bounds__(kBlock) void k_pack1(int n, float* __restrict__ sta
   if (s >= n) return;
   stage[sorted_order ? s : ids[s]] = x[s];
 }
+// ---------------------------------------------------------------------------------
+// slab halo: band selection (wave-aggregated append) and record append
+// ---------------------------------------------------------------------------------
+constexpr int kRecord = 7;  // x,y,z,vx,vy,vz,id-bits
+
+__global__ __launch_bounds__(kBlock) void k_slab_pack(DevConsts c, int side, float bound,
+                                                      const float* __restrict__ px, const float* __restrict__ py,
+                                                      const float* __restrict__ pz, const float* __restrict__ vx,
+                                                      const float* __restrict__ vy, const float* __restrict__ vz,
+                                                      const int* __restrict__ ids, float* __restrict__ out,
+                                                      int capacity, int* __restrict__ counter) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  bool take = false;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < c.n) {
+    x = px[i];
+    y = py[i];
+    z = pz[i];
+    const float p = c.slab_axis == 0 ? x : (c.slab_axis == 1 ? y : z);
+    const bool finite = (x == x) && (y == y) && (z == z);  // ghosts carry NaN after the step
+    take = finite && (side == 0 ? (p < bound) : (p >= bound));
+  }
+  const unsigned long long m = __ballot(take);
+  if (m == 0ull) return;
+  const int leader = __builtin_ctzll(m);
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __builtin_popcountll(m));
+  base = __shfl(base, leader, kWave);
+  if (take) {
+    const int d = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (d < capacity) {
+      float* r = out + (size_t)d * kRecord;
+      r[0] = x;
+      r[1] = y;
+      r[2] = z;
+      r[3] = vx[i];
+      r[4] = vy[i];
+      r[5] = vz[i];
+      r[6] = __int_as_float(ids[i]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_slab_append(int count, int at, const float* __restrict__ rec,
+                                                        float* __restrict__ px, float* __restrict__ py,
+                                                        float* __restrict__ pz, float* __restrict__ vx,
+                                                        float* __restrict__ vy, float* __restrict__ vz,
+                                                        int* __restrict__ ids) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= count) return;
+  const float* r = rec + (size_t)k * kRecord;
+  const int d = at + k;
+  px[d] = r[0];
+  py[d] = r[1];
+  pz[d] = r[2];
+  vx[d] = r[3];
+  vy[d] = r[4];
+  vz[d] = r[5];
+  ids[d] = __float_as_int(r[6]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_owned(DevConsts c, const float* __restrict__ px,
+                                                        const float* __restrict__ py, const float* __restrict__ pz,
+                                                        int* __restrict__ counter) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  const bool own = i < c.n && slab_owned(c, px[i], py[i], pz[i]);
+  const unsigned long long m = __ballot(own);
+  if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(counter, __builtin_popcountll(m));
+}
+
 __global__ __launch_bounds__(kBlock) void k_iota(int n, int* __restrict__ ids) {
   const int s = blockIdx.x * kBlock + threadIdx.x;
   if (s < n) ids[s] = s;

@@ -252,14 +252,21 @@ __global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, 
   } else {
     fx = fy = fz = 0.f;
   }
+  const bool owned = live && slab_owned(c, px, py, pz);
+  if (!owned) fx = fy = fz = vx = vy = vz = 0.f;  // keep ghosts out of the max|v|, max|F| counters
   integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats);
-  if (live) {
+  if (owned) {
     p.x[i] = px;
     p.y[i] = py;
     p.z[i] = pz;
     v.x[i] = vx;
     v.y[i] = vy;
     v.z[i] = vz;
+  } else if (live) {
+    const float qnan = __uint_as_float(0x7fc00000u);  // ghost: dropped at the next neighbour build
+    p.x[i] = qnan;
+    p.y[i] = qnan;
+    p.z[i] = qnan;
   }
 }
 
@@ -277,8 +284,9 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const i
                                                             DevStats* stats) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < c.n;
+  const bool owned = live && slab_owned(c, pin.x[i], pin.y[i], pin.z[i]);
   float fx = 0.f, fy = 0.f, fz = 0.f, px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-  if (live) {
+  if (owned) {
     fx = c.reset[0];
     fy = c.reset[1];
     fz = c.reset[2];
@@ -314,13 +322,21 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const i
     vz = vin.z[i];
   }
   integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats);
-  if (live) {
+  if (owned) {
     pout.x[i] = px;
     pout.y[i] = py;
     pout.z[i] = pz;
     vout.x[i] = vx;
     vout.y[i] = vy;
     vout.z[i] = vz;
+  } else if (live) {
+    const float qnan = __uint_as_float(0x7fc00000u);  // ghost: dropped at the next neighbour build
+    pout.x[i] = qnan;
+    pout.y[i] = qnan;
+    pout.z[i] = qnan;
+    vout.x[i] = vin.x[i];
+    vout.y[i] = vin.y[i];
+    vout.z[i] = vin.z[i];
   }
 }
 

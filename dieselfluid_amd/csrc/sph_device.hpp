@@ -35,6 +35,9 @@ struct DevConsts {
   float inv_cell;
   int dims[3];
   int ncell;
+  // slab ownership (multi-GPU): axis < 0 = everything owned
+  int slab_axis;
+  float slab_lo, slab_hi;
 };
 
 // Host-visible counters living in device memory (fluid.go:25-26, pcisph_darwin.go:46-98).
@@ -122,6 +125,13 @@ __device__ __forceinline__ int cell_of(const DevConsts& c, float x, float y, flo
   int cy = cell_coord(y, c.gmin[1], c.inv_cell, c.dims[1]);
   int cz = cell_coord(z, c.gmin[2], c.inv_cell, c.dims[2]);
   return (cz * c.dims[1] + cy) * c.dims[0] + cx;
+}
+
+// slab ownership: ghosts (outside [lo,hi) along the slab axis, or NaN) are never integrated
+__device__ __forceinline__ bool slab_owned(const DevConsts& c, float x, float y, float z) {
+  if (c.slab_axis < 0) return true;
+  const float p = c.slab_axis == 0 ? x : (c.slab_axis == 1 ? y : z);
+  return p >= c.slab_lo && p < c.slab_hi;  // false for NaN
 }
 
 // Candidate sweep: the 27 cells around (x,y,z) as 9 x-runs; thanks to the x-fastest

@@ -45,8 +45,8 @@ class SPHEngine:
         rc = self._L.dsl_create(C.byref(params), int(device), C.byref(self._h))
         if rc:
             raise DslError(f"dsl_create failed ({rc}): {self._L.dsl_last_error(None).decode()}")
-        self.n = int(params.n_particles)
         self.device = device
+        self.capacity = int(params.capacity) if params.capacity else int(params.n_particles)
 
     # -- plumbing -----------------------------------------------------------------
     def _ck(self, rc):
@@ -71,6 +71,18 @@ class SPHEngine:
         self.close()
 
     @property
+    def n(self) -> int:
+        """live particle count (changes only in slab mode)"""
+        n = C.c_int(0)
+        self._ck(self._L.dsl_get_count(self._h, C.byref(n), None))
+        return n.value
+
+    def n_owned(self) -> int:
+        n, o = C.c_int(0), C.c_int(0)
+        self._ck(self._L.dsl_get_count(self._h, C.byref(n), C.byref(o)))
+        return o.value
+
+    @property
     def params(self) -> Params:
         p = Params()
         self._ck(self._L.dsl_get_params(self._h, C.byref(p)))
@@ -90,10 +102,31 @@ class SPHEngine:
 
     def download(self, name: str, sorted_order: bool = False) -> np.ndarray:
         b = BUF[name]
-        out = np.empty(self.n * _COMPS[b], dtype=np.float32)
+        n = self.n
+        out = np.empty(n * _COMPS[b], dtype=np.float32)
         fn = self._L.dsl_download_sorted if sorted_order else self._L.dsl_download
         self._ck(fn(self._h, b, _fp(out), out.size))
-        return out.reshape(self.n, 3) if _COMPS[b] == 3 else out
+        return out.reshape(n, 3) if _COMPS[b] == 3 else out
+
+    def set_ids(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        self._ck(self._L.dsl_set_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
+
+    def reset_forces(self):
+        self._ck(self._L.dsl_reset_forces(self._h))
+
+    # -- multi-GPU slabs (device record buffers are raw pointers, e.g. tensor.data_ptr()) --
+    def slab_config(self, axis: int, lo: float, hi: float):
+        self._ck(self._L.dsl_slab_config(self._h, int(axis), C.c_float(lo), C.c_float(hi)))
+
+    def slab_pack(self, side: int, width: float, dev_ptr: int, capacity: int) -> int:
+        cnt = C.c_int(0)
+        self._ck(self._L.dsl_slab_pack(self._h, int(side), C.c_float(width), C.c_void_p(dev_ptr), int(capacity),
+                                       C.byref(cnt)))
+        return cnt.value
+
+    def slab_append(self, dev_ptr: int, count: int):
+        self._ck(self._L.dsl_slab_append(self._h, C.c_void_p(dev_ptr), int(count)))
 
     def download_ids(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.int32)

@@ -62,6 +62,32 @@ def dambreak_positions(n3: int, dx: float, jitter: float = 0.05, seed: int = 123
     return (base + jit.reshape(-1, 3)).astype(f32)
 
 
+def dambreak_slab_ids(n3: int, axis: int, l0: int, l1: int) -> np.ndarray:
+    """ids (k + n3*(i*n3 + j)) of the lattice layers l0 <= index < l1 along `axis`
+    (0: i/x, 1: j/y, 2: k/z), ascending."""
+    rng = [np.arange(n3)] * 3
+    rng = list(rng)
+    rng[axis] = np.arange(l0, l1)
+    i, j, k = np.meshgrid(rng[0], rng[1], rng[2], indexing="ij")
+    ids = (k + n3 * (i * n3 + j)).reshape(-1)
+    return np.sort(ids).astype(np.int32)
+
+
+def dambreak_positions_ids(n3: int, dx: float, ids, jitter: float = 0.05, seed: int = 1234) -> np.ndarray:
+    """dambreak_positions restricted to the given particle ids (same values bit for bit)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    k = ids % n3
+    j = (ids // n3) % n3
+    i = ids // (n3 * n3)
+    ctr = (3 * ids[:, None] + np.arange(3)[None, :]).reshape(-1).astype(np.uint64)
+    r = _splitmix64(seed, ctr)
+    u = ((r >> np.uint64(40)).astype(f32) * f32(1.0 / 16777216.0)).astype(f32)
+    jit = ((u * f32(2.0) - f32(1.0)).astype(f32) * f32(f32(jitter) * f32(dx))).astype(f32)
+    ijk = np.stack([i, j, k], axis=-1).astype(f32)
+    base = ((ijk + f32(0.5)).astype(f32) * f32(dx)).astype(f32)
+    return (base + jit.reshape(-1, 3)).astype(f32)
+
+
 def lattice_rest_density(h_over_dx: float, mass: float, dx: float) -> float:
     """Density the reference kernel (kernel/std_kernel.go:33-39) gives an interior particle
     of a perfect cubic lattice, self term excluded as in SPHField.Density."""

@@ -97,7 +97,9 @@ typedef struct dsl_params {
   float grid_min[3], grid_max[3];
   int32_t neigh_mode; /* DSL_NEIGH_GRID */
   int32_t math_mode;  /* DSL_MATH_*     */
-  int32_t reserved[8];
+  int32_t capacity;   /* particle slots to allocate (>= n_particles); 0 = n_particles.
+                         Slab ranks need room for migrants and ghosts. */
+  int32_t reserved[7];
 } dsl_params;
 
 /* Counters the reference keeps on the host (fluid.go:25-26,186-191) plus the PCISPH loop
@@ -190,6 +192,33 @@ int dsl_timing_get(dsl_handle *h, int kernel_id, double *avg_ms, int64_t *launch
 int dsl_download_sorted(dsl_handle *h, int buffer, float *host, size_t count);
 int dsl_download_ids(dsl_handle *h, int32_t *ids, size_t count);
 int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
+
+/* ---- multi-GPU: spatial slabs, one process per GPU -----------------------------------
+ * The reference has no multi-process path; these entry points are
+ * what a host needs to run one slab per GPU and exchange a halo with its two neighbours
+ * (over RCCL, by whatever transport the host owns).  A record is 7 floats:
+ * x,y,z,vx,vy,vz and the global particle id as raw int32 bits.
+ *
+ * dsl_slab_config : this handle owns [lo,hi) along `axis` (use -INFINITY / INFINITY at the
+ *                   domain ends); particles outside are ghosts: they take part in the
+ *                   neighbour sums but are not integrated and are dropped at the next
+ *                   neighbour build.
+ * dsl_slab_pack   : copies every owned particle with pos[axis] < lo+width (side 0) or
+ *                   >= hi-width (side 1) -- migrants included -- to a DEVICE buffer of
+ *                   `capacity` records; *count is the number selected (blocking).
+ * dsl_slab_append : appends `count` records from a DEVICE buffer after the current
+ *                   particles; they are owned if inside [lo,hi), ghosts otherwise.
+ * After appending, dsl_build_neighbours drops the previous step's ghosts (the integrate
+ * kernels mark them with NaN positions) and updates the live count.  A particle that has
+ * just crossed the plane stays one more step as a ghost of its old owner. */
+int dsl_slab_config(dsl_handle *h, int axis, float lo, float hi);
+int dsl_slab_pack(dsl_handle *h, int side, float width, float *dev_records, int capacity, int *count);
+int dsl_slab_append(dsl_handle *h, const float *dev_records, int count);
+int dsl_get_count(dsl_handle *h, int *n_live, int *n_owned);
+/* global particle ids of the current slots (host order of dsl_upload); default 0..n-1 */
+int dsl_set_ids(dsl_handle *h, const int32_t *ids, size_t count);
+/* Marks every force as equal to force_reset (the state Update leaves, fluid.go:193) */
+int dsl_reset_forces(dsl_handle *h);
 
 /* Error text of the last failing call on this handle (NULL handle: creation errors).
  * Replaces log.Fatalf in compute/gpu/gpu.go:52,66,234,339: the process is never aborted. */
