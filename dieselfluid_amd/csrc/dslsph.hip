@@ -24,7 +24,7 @@
 #include <utility>
 #include <vector>
 
-#include "kernels_sph.hpp"
+#include "kernels_tiled.hpp"
 
 using namespace dsl;
 
@@ -40,6 +40,8 @@ struct dsl_handle {
   int n = 0, cap = 0, ncell = 0, ncell_pad = 0, nscan = 0;
   bool ids_global = false;  // dsl_set_ids replaced the host-order map
   int* dcounter = nullptr;
+  TileGrid tg{};
+  int *tiles = nullptr, *n_tiles = nullptr;
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -296,6 +298,14 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (!h->forces_uniform) h->cur_f ^= 1;
   if (h->pci_active) h->cur_pci ^= 1;
   h->grid_valid = true;
+  if (h->prm.math_mode == DSL_MATH_FAST) {
+    HIP_TRY(h, hipMemsetAsync(h->n_tiles, 0, sizeof(int), h->stream));
+    rc = timed(h, DSL_K_TILE_LIST, [&] {
+      hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
+                         h->cell_start, h->tiles, h->n_tiles);
+    });
+    if (rc) return rc;
+  }
   if (h->c.slab_axis >= 0) {
     // departed particles and stale ghosts were sorted into the extra bucket `ncell`
     int live = 0;
@@ -316,9 +326,33 @@ int by_math(dsl_handle* h, Launch&& l) {
   return DSL_OK;
 }
 
+// FAST mode uses the LDS-tiled kernels; the reference's running-mass viscosity recurrence
+// (sph_field.go:265) is order- and membership-dependent for m != 1 and stays on the
+// branching lane-per-particle kernel.
+bool use_tiled(const dsl_handle* h) {
+  if (h->prm.math_mode != DSL_MATH_FAST) return false;
+  if (h->c.wcsph_viscosity && h->c.visc_running_mass && h->c.mass != 1.0f) return false;
+  return true;
+}
+int persistent_grid(const dsl_handle* h, int blocks_per_cu) {
+  int g = 256 * blocks_per_cu;
+  if (g > h->tg.ntiles) g = h->tg.ntiles;
+  g = (g + 7) & ~7;  // the XCD walk deals tiles in eighths
+  return g < 8 ? 8 : g;
+}
+
 int density_pass(dsl_handle* h) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
+  if (h->prm.math_mode == DSL_MATH_FAST) {
+    int rc = timed(h, DSL_K_DENSITY, [&] {
+      hipLaunchKernelGGL(k_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles,
+                         h->n_tiles, h->cell_start, p, h->rho, h->pterm);
+    });
+    if (rc) return rc;
+    h->dens_fresh = true;
+    return DSL_OK;
+  }
   int rc = timed(h, DSL_K_DENSITY, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
@@ -337,7 +371,21 @@ int force_integrate(dsl_handle* h) {
   Soa3 po = mpos(h, o), vo = mvel(h, o);
   const int uni = h->forces_uniform ? 1 : 0;
   const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
-  int rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
+  int rc = DSL_OK;
+  if (use_tiled(h)) {
+    rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
+      dim3 g(persistent_grid(h, 2)), b(kTBlock);
+#define DSL_LAUNCH_FT(GG, VV)                                                                                   \
+  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tiles, h->n_tiles,    \
+                     h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats)
+      if (G && V) DSL_LAUNCH_FT(true, true);
+      else if (G) DSL_LAUNCH_FT(true, false);
+      else if (V) DSL_LAUNCH_FT(false, true);
+      else DSL_LAUNCH_FT(false, false);
+#undef DSL_LAUNCH_FT
+    });
+  } else
+  rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
     by_math(h, [&](auto fast) {
       constexpr bool FAST = decltype(fast)::value;
       dim3 g(grid_for(h->n)), b(kBlock);
@@ -440,6 +488,8 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->stage);
   (void)hipFree(h->dstats);
   (void)hipFree(h->dcounter);
+  (void)hipFree(h->tiles);
+  (void)hipFree(h->n_tiles);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (auto& v : h->pending)
     for (auto& pr : v) {
@@ -555,6 +605,11 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
       (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)))
     return bail(rc);
+  h->tg.tnx = (h->c.dims[0] + kTB - 1) / kTB;
+  h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
+  h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
+  h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
+  if ((rc = dev_alloc(h, &h->tiles, (size_t)h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 4))) return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
   for (int k = 0; k < 6 && me == hipSuccess; ++k) me = hipMemsetAsync(h->pv[0][k], 0, n * sizeof(float), h->stream);

@@ -198,6 +198,40 @@ __global__ __launch_bounds__(kBlock) void k_external(int n, Soa3 f, float ex, fl
 }
 
 // U: SPH.Update (fluid.go:175-197) for one particle, then the build-defined wall box.
+__device__ __forceinline__ void integrate_core(const DevConsts& c, float fx, float fy, float fz, float& px, float& py,
+                                               float& pz, float& vx, float& vy, float& vz, unsigned int& vbits,
+                                               unsigned int& fbits) {
+  const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
+  const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
+  vx += dvx;
+  vy += dvy;
+  vz += dvz;
+  const float dpx = vx * c.dt, dpy = vy * c.dt, dpz = vz * c.dt;
+  px += dpx;
+  py += dpy;
+  pz += dpz;
+  const float vm = dsl_sqrt<false>(dist2<false>(vx, vy, vz));
+  const float fm = dsl_sqrt<false>(dist2<false>(fx, fy, fz));
+  const unsigned int vb = nonneg_bits(vm), fb = nonneg_bits(fm);
+  vbits = vb > vbits ? vb : vbits;
+  fbits = fb > fbits ? fb : fbits;
+  if (c.walls) {
+    float* P[3] = {&px, &py, &pz};
+    float* V[3] = {&vx, &vy, &vz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (*P[a] < c.bmin[a]) {
+        *P[a] = c.bmin[a];
+        if (*V[a] < 0.0f) *V[a] = -*V[a] * c.rest;
+      }
+      if (*P[a] > c.bmax[a]) {
+        *P[a] = c.bmax[a];
+        if (*V[a] > 0.0f) *V[a] = -*V[a] * c.rest;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void integrate_one(const DevConsts& c, float fx, float fy, float fz, float& px, float& py,
                                               float& pz, float& vx, float& vy, float& vz, DevStats* stats) {
   const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;

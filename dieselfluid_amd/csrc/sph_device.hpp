@@ -173,13 +173,18 @@ __device__ __forceinline__ float dist2(float dx, float dy, float dz) {
   }
 }
 
-// wave-level max of non-negative float bit patterns, one atomic per wave
+// wave-level max of non-negative float bit patterns.  The global is only touched when it
+// would grow: same-address atomics serialise in L2 (500k of them per 16M-particle step cost
+// milliseconds, profiles/r01_v2_pmc.md), while the running maximum settles after a few waves.
 __device__ __forceinline__ void wave_atomic_max(unsigned int* addr, unsigned int v) {
   for (int off = kWave / 2; off > 0; off >>= 1) {
     unsigned int o = __shfl_xor(v, off, kWave);
     v = o > v ? o : v;
   }
-  if ((threadIdx.x & (kWave - 1)) == 0 && v != 0u) atomicMax(addr, v);
+  if ((threadIdx.x & (kWave - 1)) == 0 && v != 0u) {
+    const unsigned int cur = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v > cur) atomicMax(addr, v);
+  }
 }
 __device__ __forceinline__ unsigned int nonneg_bits(float v) {
   return v > 0.0f ? __float_as_uint(v) : 0u;  // NaN and <=0 contribute nothing

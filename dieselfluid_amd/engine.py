@@ -20,7 +20,7 @@ BUF = {
 _COMPS = {0: 3, 1: 3, 2: 3, 3: 1, 4: 1, 5: 3, 6: 3}
 KERNEL_IDS = {
     "cell_rank": 0, "scan": 1, "scatter": 2, "density": 3, "force_integrate": 4, "pressure": 5, "viscous": 6,
-    "gradient": 7, "external": 8, "update": 9, "pci_predict": 10, "pci_density": 11,
+    "gradient": 7, "external": 8, "update": 9, "pci_predict": 10, "pci_density": 11, "tile_list": 12,
 }
 
 

@@ -128,7 +128,8 @@ enum {
   DSL_K_UPDATE = 9,
   DSL_K_PCI_PREDICT = 10,
   DSL_K_PCI_DENSITY = 11,
-  DSL_K_COUNT = 12
+  DSL_K_TILE_LIST = 12, /* non-empty 4x4x4-cell tiles for the LDS-tiled kernels */
+  DSL_K_COUNT = 13
 };
 
 typedef struct dsl_handle dsl_handle;
