@@ -83,7 +83,15 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL over xGMI; DSL_BENCH_BACKEND=gloo only exists to rehearse this code path with
+        # several ranks on a one-GPU box (every rank then uses cuda:DSL_BENCH_DEVICE)
+        backend = os.environ.get("DSL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = int(os.environ.get("DSL_BENCH_DEVICE", "0"))
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
 
     from dieselfluid_amd import SPHEngine, scenes
 
@@ -122,7 +130,7 @@ def main():
     for e in engines:
         e.timing_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

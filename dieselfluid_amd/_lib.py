@@ -13,7 +13,10 @@ _LIB = os.path.join(_PKG, "lib", "libdslsph.so")
 _SRC_DIR = os.path.join(_PKG, "csrc")
 _HDR = os.path.join(_ROOT, "include", "dslsph.h")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall"]
+# -fno-slp-vectorize: packed FP32 (v_pk_*) issues slower than two scalar ops once operands
+# are distinct registers (tools/valu_rate.hip), so keep the compiler from forming them.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+               "-std=c++17", "-Wall"]
 
 
 class DslError(RuntimeError):

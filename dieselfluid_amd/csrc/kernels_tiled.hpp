@@ -169,8 +169,23 @@ struct TileWalk {
   }
 };
 
+// q = clamp(a*b + c, 0, 1) in ONE instruction (VOP3 clamp output modifier).  The kernel
+// weights are q = 1 - r^2/h^2 or 1 - r/h, never above 1, so this is exactly max(q, 0).
+__device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 // ---------------------------------------------------------------------------------
 // D (tiled): densities + P/rho^2
+//
+// Candidate coordinates are staged RELATIVE TO THE TILE CENTRE together with their squared
+// norm w = |x|^2, so that r^2 = |xi|^2 + w_j - 2 xi.xj costs one add and three fma instead of
+// three subtractions and three fma (the kernel is bound by FP32 issue, profiles/r01_v3_pmc.md).
+// Tile-relative values stay below 3.5 cells, which bounds the cancellation error of the
+// expanded form at ~2e-6 h^2 -- inside the FAST-mode tolerance, and invisible to the cut-off
+// (a candidate that far out contributes ~1e-12).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
                                                           const int* __restrict__ n_tiles,
@@ -186,12 +201,19 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     __syncthreads();  // previous tile's LDS is no longer read
     tile_setup(c, tg, tile, cell_start, m);
     const bool ovf = m.overflow != 0;
+    // tile centre in world coordinates
+    const float ox = c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
+    const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
+    const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
       for (int r = wid; r < kTRows; r += kTBlock / kWave) {
         const int gs = m.row_gs[r], len = m.row_len[r], ls = m.row_lds[r];
         for (int i = lane; i < len + kTPad; i += kWave) {
-          float4 v = make_float4(kFar, kFar, kFar, 0.f);
-          if (i < len) v = make_float4(p.x[gs + i], p.y[gs + i], p.z[gs + i], 0.f);
+          float4 v = make_float4(kFar, kFar, kFar, 3.0f * kFar * kFar);
+          if (i < len) {
+            const float x = p.x[gs + i] - ox, y = p.y[gs + i] - oy, z = p.z[gs + i] - oz;
+            v = make_float4(x, y, z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+          }
           A[ls + i] = v;
         }
       }
@@ -204,10 +226,12 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       int srow, off;
       tile_target(m, t, srow, off);
       const int g = m.row_gs[srow] + off;
-      float acc = 0.0f;
+      float acc = 0.0f, acc1 = 0.0f;
       if (!ovf) {
         const float4 me = A[m.row_lds[srow] + off];
-        const int lx = cell_coord(me.x, c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+        const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
+        const float ninv = -c.inv_hh;
+        const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
 #pragma unroll 1
         for (int dz = -kTH; dz <= kTH; dz += kTH) {
 #pragma unroll 1
@@ -220,16 +244,16 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const float4 cnd = A[j + u];
-                const float dx = me.x - cnd.x, dy2 = me.y - cnd.y, dz2 = me.z - cnd.z;
-                // cnd.w is 0 in every record; using it keeps the read a single ds_read_b128
-                const float r2 = __builtin_fmaf(dz2, dz2, __builtin_fmaf(dy2, dy2, __builtin_fmaf(dx, dx, cnd.w)));
-                const float q = fmaxf(__builtin_fmaf(-r2, c.inv_hh, 1.0f), 0.0f);
-                acc = __builtin_fmaf(q, q, acc);
+                // r^2 = |xi|^2 + |xj|^2 - 2 xi.xj ; q = clamp(1 - r^2/h^2)
+                const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
+                const float q = fma_clamp01(r2, ninv, 1.0f);
+                if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+                else acc = __builtin_fmaf(q, q, acc);
               }
             }
           }
         }
-        acc -= 1.0f;  // the particle met itself once (q = 1)
+        acc = (acc + acc1) - 1.0f;  // the particle met itself once (q = 1)
         acc = acc * (c.mass * c.A);
       } else {
         const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
@@ -312,6 +336,8 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         if (!ovf) {
           if constexpr (WANT_G || WANT_V) {
             const float pti = WANT_G ? pterm[g] : 0.f;
+            const float ninvh = -c.inv_h;
+            float lw_ = 0.f;
             const int lx = cell_coord(px, c.gmin[0], c.inv_cell, c.dims[0]) - x0;
 #pragma unroll 1
             for (int dz = -kTH; dz <= kTH; dz += kTH) {
@@ -330,7 +356,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                     r2 = fmaxf(r2, 1.0e-30f);  // the particle itself: keeps rsq finite, all terms stay 0
                     const float rinv = __builtin_amdgcn_rsqf(r2);
                     const float dist = r2 * rinv;
-                    const float q = fmaxf(__builtin_fmaf(-dist, c.inv_h, 1.0f), 0.0f);
+                    const float q = fma_clamp01(dist, ninvh, 1.0f);
                     if constexpr (WANT_G) {
                       const float k = (q * q) * (pti + a.w) * rinv;
                       gx = __builtin_fmaf(dx, k, gx);
@@ -338,15 +364,22 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                       gz = __builtin_fmaf(dzz, k, gz);
                     }
                     if constexpr (WANT_V) {
+                      // sum_j (v_j - v_i) w_j = sum_j v_j w_j - v_i sum_j w_j
                       const float4 b = B[j + u];
                       const float w = q * b.w;
-                      lx_ = __builtin_fmaf(b.x - vx, w, lx_);
-                      ly_ = __builtin_fmaf(b.y - vy, w, ly_);
-                      lz_ = __builtin_fmaf(b.z - vz, w, lz_);
+                      lx_ = __builtin_fmaf(b.x, w, lx_);
+                      ly_ = __builtin_fmaf(b.y, w, ly_);
+                      lz_ = __builtin_fmaf(b.z, w, lz_);
+                      lw_ += w;
                     }
                   }
                 }
               }
+            }
+            if constexpr (WANT_V) {
+              lx_ = __builtin_fmaf(-vx, lw_, lx_);
+              ly_ = __builtin_fmaf(-vy, lw_, ly_);
+              lz_ = __builtin_fmaf(-vz, lw_, lz_);
             }
             // constant factors taken out of the sums: -O1D = -B q^2, O2D = C q, times m
             const float sg = -c.B;

@@ -51,8 +51,9 @@ class HipSlabEngine:
         if records.shape[0] == 0:
             return
         r = records.to(self.dev, dtype=torch.float32).contiguous()
+        # the engine runs on torch's current stream, so the caching allocator's stream-ordered
+        # reuse keeps r's memory valid until the append kernel has run
         self.eng.slab_append(r.data_ptr(), r.shape[0])
-        torch.cuda.current_stream(self.dev).synchronize()  # r may be freed after return
 
     def nn(self):
         self.eng.nn()
