@@ -78,6 +78,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("DSL_BENCH_BACKEND", "nccl")
+    if backend != "nccl":  # rehearsal of the multi-rank path on a one-GPU box
+        local_rank = int(os.environ.get("DSL_BENCH_DEVICE", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -85,12 +88,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL over xGMI; DSL_BENCH_BACKEND=gloo only exists to rehearse this code path with
         # several ranks on a one-GPU box (every rank then uses cuda:DSL_BENCH_DEVICE)
-        backend = os.environ.get("DSL_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            local_rank = int(os.environ.get("DSL_BENCH_DEVICE", "0"))
-            torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
 
     from dieselfluid_amd import SPHEngine, scenes

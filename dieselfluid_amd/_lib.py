@@ -75,6 +75,7 @@ EXPORTS = {
     "dsl_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "dsl_sync": (C.c_int, [_vp]),
     "dsl_set_stream": (C.c_int, [_vp, _vp]),
+    "dsl_use_own_stream": (C.c_int, [_vp]),
     "dsl_timing_enable": (C.c_int, [_vp, C.c_int]),
     "dsl_timing_reset": (C.c_int, [_vp]),
     "dsl_timing_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -82,8 +83,9 @@ EXPORTS = {
     "dsl_download_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_download_cell_start": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_slab_config": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float]),
-    "dsl_slab_pack": (C.c_int, [_vp, C.c_int, C.c_float, _vp, C.c_int, C.POINTER(C.c_int)]),
+    "dsl_slab_pack": (C.c_int, [_vp, C.c_float, _vp, _vp, C.c_int]),
     "dsl_slab_append": (C.c_int, [_vp, _vp, C.c_int]),
+    "dsl_slab_overflow": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dsl_get_count": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dsl_set_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_reset_forces": (C.c_int, [_vp]),

@@ -40,6 +40,7 @@ struct dsl_handle {
   int n = 0, cap = 0, ncell = 0, ncell_pad = 0, nscan = 0;
   bool ids_global = false;  // dsl_set_ids replaced the host-order map
   int* dcounter = nullptr;
+  int* dn = nullptr;  // slab mode: [0] live particle count, [1],[2] band counters, [3] overflow high-water mark
   TileGrid tg{};
   int *tiles = nullptr, *n_tiles = nullptr;
   // SoA state
@@ -86,6 +87,9 @@ int fail(dsl_handle* h, int code, const std::string& msg) {
   } while (0)
 
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+// number of slots a per-particle launch has to cover: exact without slabs; in slab mode the
+// live count lives on the device, so cover the whole capacity (idle blocks exit at once)
+inline int launch_n(const dsl_handle* h);
 
 // Fills the device constants from the parameter block; host arithmetic mirrors
 // kernel.Build_Kernel (kernel/std_kernel.go:20-31) in float32.
@@ -147,8 +151,11 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   c.slab_axis = -1;
   c.slab_lo = -INFINITY;
   c.slab_hi = INFINITY;
+  c.n_ptr = nullptr;
   return DSL_OK;
 }
+
+inline int launch_n(const dsl_handle* h) { return h->c.n_ptr ? h->cap : h->n; }
 
 template <class T>
 int dev_alloc(dsl_handle* h, T** p, size_t count) {
@@ -215,7 +222,7 @@ int materialise_forces(dsl_handle* h) {
   if (!h->forces_uniform) return DSL_OK;
   Soa3 f = mfrc(h);
   const DevConsts& c = h->c;
-  hipLaunchKernelGGL(k_fill3, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->n, f.x, f.y, f.z, c.reset[0],
+  hipLaunchKernelGGL(k_fill3, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, launch_n(h), f.x, f.y, f.z, c.reset[0],
                      c.reset[1], c.reset[2]);
   HIP_TRY(h, hipGetLastError());
   h->forces_uniform = false;
@@ -223,7 +230,7 @@ int materialise_forces(dsl_handle* h) {
 }
 int materialise_press(dsl_handle* h) {
   if (!h->press_zero) return DSL_OK;
-  HIP_TRY(h, hipMemsetAsync(h->press, 0, sizeof(float) * (size_t)h->n, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->press, 0, sizeof(float) * (size_t)launch_n(h), h->stream));
   h->press_zero = false;
   return DSL_OK;
 }
@@ -231,7 +238,7 @@ int materialise_press(dsl_handle* h) {
 // cell hash -> histogram -> prefix sum -> counting-sort scatter.  carry_derived also
 // permutes rho/pterm/press so that an explicit dsl_build_neighbours keeps them usable.
 int build_grid(dsl_handle* h, bool carry_derived) {
-  const int n = h->n;
+  const int n = launch_n(h);
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
   HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
@@ -270,7 +277,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   a.ids_src = h->ids[h->cur_ids];
   a.ids_dst = h->ids[h->cur_ids ^ 1];
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, a, h->cellid, h->rank,
+    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, h->cellid, h->rank,
                        h->cell_start);
   });
   if (rc) return rc;
@@ -285,7 +292,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
       b.nf = 1;
       b.ids_src = h->ids[h->cur_ids];      // ids re-scattered identically; harmless
       b.ids_dst = h->ids[h->cur_ids ^ 1];
-      hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, b, h->cellid, h->rank,
+      hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, b, h->cellid, h->rank,
                          h->cell_start);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipMemcpyAsync(arr, h->scratch1, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
@@ -306,13 +313,10 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     });
     if (rc) return rc;
   }
-  if (h->c.slab_axis >= 0) {
-    // departed particles and stale ghosts were sorted into the extra bucket `ncell`
-    int live = 0;
-    HIP_TRY(h, hipMemcpyAsync(&live, h->cell_start + h->ncell, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    h->n = live;
-    h->c.n = live;
+  if (h->c.n_ptr) {
+    // stale ghosts were sorted into the extra bucket `ncell`; the live count stays on the device
+    hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, h->stream, h->dn, h->cell_start + h->ncell);
+    HIP_TRY(h, hipGetLastError());
   }
   return DSL_OK;
 }
@@ -355,7 +359,7 @@ int density_pass(dsl_handle* h) {
   }
   int rc = timed(h, DSL_K_DENSITY, [&] {
     by_math(h, [&](auto fast) {
-      hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+      hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
                          h->cell_start, p, h->rho, h->pterm);
     });
   });
@@ -388,7 +392,7 @@ int force_integrate(dsl_handle* h) {
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
     by_math(h, [&](auto fast) {
       constexpr bool FAST = decltype(fast)::value;
-      dim3 g(grid_for(h->n)), b(kBlock);
+      dim3 g(grid_for(launch_n(h))), b(kBlock);
 #define DSL_LAUNCH_FI(GG, VV)                                                                                    \
   hipLaunchKernelGGL((k_force_integrate<FAST, GG, VV>), g, b, 0, h->stream, c, h->cell_start, p, v, h->rho,     \
                      h->pterm, f, uni, po, vo, h->dstats)
@@ -413,7 +417,7 @@ int gradient_pass(dsl_handle* h, int honour_done) {
   Soa3 f = mfrc(h);
   return timed(h, DSL_K_GRADIENT, [&] {
     by_math(h, [&](auto fast) {
-      hipLaunchKernelGGL((k_gradient<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+      hipLaunchKernelGGL((k_gradient<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
                          h->cell_start, p, h->rho, h->pterm, f, h->dstats, honour_done);
     });
   });
@@ -425,7 +429,7 @@ int viscous_pass(dsl_handle* h) {
   Soa3 f = mfrc(h);
   return timed(h, DSL_K_VISCOUS, [&] {
     by_math(h, [&](auto fast) {
-      hipLaunchKernelGGL((k_viscous<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+      hipLaunchKernelGGL((k_viscous<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
                          h->cell_start, p, v, h->rho, f);
     });
   });
@@ -437,12 +441,24 @@ int update_pass(dsl_handle* h) {
   CSoa3 f = cfrc(h);
   const int uni = h->forces_uniform ? 1 : 0;
   int rc = timed(h, DSL_K_UPDATE, [&] {
-    hipLaunchKernelGGL(k_update, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c, p, v, f, uni, h->dstats);
+    hipLaunchKernelGGL(k_update, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c, p, v, f, uni, h->dstats);
   });
   if (rc) return rc;
   h->forces_uniform = true;
   h->press_zero = true;
   h->grid_valid = false;
+  return DSL_OK;
+}
+
+// exact live count on the host (slab mode: one small device read)
+int host_count(dsl_handle* h, int* out) {
+  if (!h->c.n_ptr) {
+    *out = h->n;
+    return DSL_OK;
+  }
+  HIP_TRY(h, hipMemcpyAsync(out, h->dn, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->n = *out;
   return DSL_OK;
 }
 
@@ -488,6 +504,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->stage);
   (void)hipFree(h->dstats);
   (void)hipFree(h->dcounter);
+  (void)hipFree(h->dn);
   (void)hipFree(h->tiles);
   (void)hipFree(h->n_tiles);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
@@ -603,7 +620,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
-      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)))
+      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 4)))
     return bail(rc);
   h->tg.tnx = (h->c.dims[0] + kTB - 1) / kTB;
   h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
@@ -658,6 +675,7 @@ int dsl_set_params(dsl_handle* h, const dsl_params* p) {
   c.slab_axis = h->c.slab_axis;
   c.slab_lo = h->c.slab_lo;
   c.slab_hi = h->c.slab_hi;
+  c.n_ptr = h->c.n_ptr;
   if (std::memcmp(c.reset, h->c.reset, sizeof(c.reset)) != 0 && h->forces_uniform) {
     if (int rc = materialise_forces(h)) return rc;  // keep the old implicit value
   }
@@ -676,7 +694,13 @@ int dsl_get_params(dsl_handle* h, dsl_params* out) {
 int dsl_set_stream(dsl_handle* h, void* s) {
   CHECK_HANDLE(h);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  h->stream = s ? (hipStream_t)s : h->own_stream;
+  h->stream = (hipStream_t)s;  // NULL is HIP's default (null) stream, a perfectly valid choice
+  return DSL_OK;
+}
+int dsl_use_own_stream(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->stream = h->own_stream;
   return DSL_OK;
 }
 
@@ -684,7 +708,9 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
   CHECK_HANDLE(h);
   BufInfo bi;
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_upload: bad buffer id or null pointer");
-  const size_t n = (size_t)h->n;
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;
+  const size_t n = (size_t)ncur;
   if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_upload: count does not match the buffer size");
   if (h->ids_global) return fail(h, DSL_ERR_INVALID, "dsl_upload: host order is gone after dsl_set_ids");
   HIP_TRY(h, hipMemcpyAsync(h->stage, host, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -744,7 +770,9 @@ static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, i
   CHECK_HANDLE(h);
   BufInfo bi;
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_download: bad buffer id or null pointer");
-  const size_t n = (size_t)h->n;
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;
+  const size_t n = (size_t)ncur;
   if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_download: count does not match the buffer size");
   if (h->ids_global && !sorted_order)
     return fail(h, DSL_ERR_INVALID, "dsl_download: host order is gone after dsl_set_ids; use dsl_download_sorted + dsl_download_ids");
@@ -796,7 +824,9 @@ int dsl_download_sorted(dsl_handle* h, int buffer, float* host, size_t count) {
 }
 int dsl_download_ids(dsl_handle* h, int32_t* ids, size_t count) {
   CHECK_HANDLE(h);
-  if (!ids || count != (size_t)h->n) return fail(h, DSL_ERR_INVALID, "dsl_download_ids: bad argument");
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;
+  if (!ids || count != (size_t)ncur) return fail(h, DSL_ERR_INVALID, "dsl_download_ids: bad argument");
   HIP_TRY(h, hipMemcpyAsync(ids, h->ids[h->cur_ids], count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return DSL_OK;
@@ -826,7 +856,7 @@ int dsl_pressure_pass(dsl_handle* h) {
   const DevConsts& c = h->c;
   int rc = timed(h, DSL_K_PRESSURE, [&] {
     by_math(h, [&](auto fast) {
-      hipLaunchKernelGGL((k_pressure<decltype(fast)::value>), dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, c,
+      hipLaunchKernelGGL((k_pressure<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
                          h->rho, h->press);
     });
   });
@@ -848,7 +878,7 @@ int dsl_external_pass(dsl_handle* h, const float f[3]) {
   if (int rc = materialise_forces(h)) return rc;
   Soa3 F = mfrc(h);
   return timed(h, DSL_K_EXTERNAL, [&] {
-    hipLaunchKernelGGL(k_external, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->n, F, f[0], f[1], f[2]);
+    hipLaunchKernelGGL(k_external, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, launch_n(h), F, f[0], f[1], f[2]);
   });
 }
 
@@ -935,47 +965,49 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
   CHECK_HANDLE(h);
   if (axis < -1 || axis > 2 || !(lo < hi)) return fail(h, DSL_ERR_INVALID, "dsl_slab_config: bad axis or empty range");
   if (h->pci_active) return fail(h, DSL_ERR_UNSUPPORTED, "slabs are implemented for the WCSPH step only");
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;
   h->c.slab_axis = axis;
   h->c.slab_lo = axis < 0 ? -INFINITY : lo;
   h->c.slab_hi = axis < 0 ? INFINITY : hi;
+  if (axis >= 0) {
+    const int init[4] = {ncur, 0, 0, 0};
+    HIP_TRY(h, hipMemcpyAsync(h->dn, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->c.n_ptr = h->dn;
+  } else {
+    h->c.n_ptr = nullptr;
+    h->c.n = ncur;
+  }
   h->grid_valid = false;
   return DSL_OK;
 }
 
-int dsl_slab_pack(dsl_handle* h, int side, float width, float* dev_records, int capacity, int* count) {
+int dsl_slab_pack(dsl_handle* h, float width, float* dev_lo, float* dev_hi, int capacity) {
   CHECK_HANDLE(h);
-  if (h->c.slab_axis < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: no slab configured");
-  if (!dev_records || !count || capacity < 0 || (side != 0 && side != 1) || !(width >= 0.0f))
-    return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: bad argument");
-  const float bound = side == 0 ? h->c.slab_lo + width : h->c.slab_hi - width;
-  HIP_TRY(h, hipMemsetAsync(h->dcounter, 0, sizeof(int), h->stream));
+  if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: no slab configured");
+  if ((!dev_lo && !dev_hi) || capacity < 0 || !(width >= 0.0f)) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: bad argument");
+  HIP_TRY(h, hipMemsetAsync(h->dn + 1, 0, 2 * sizeof(int), h->stream));
   CSoa3 p = cpos(h), v = cvel(h);
-  if (h->n > 0) {
-    hipLaunchKernelGGL(k_slab_pack, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->c, side, bound, p.x, p.y, p.z,
-                       v.x, v.y, v.z, h->ids[h->cur_ids], dev_records, capacity, h->dcounter);
-    HIP_TRY(h, hipGetLastError());
-  }
-  int cnt = 0;
-  HIP_TRY(h, hipMemcpyAsync(&cnt, h->dcounter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  *count = cnt;
-  if (cnt > capacity) return fail(h, DSL_ERR_NOMEM, "dsl_slab_pack: band does not fit the record buffer");
+  hipLaunchKernelGGL(k_slab_pack, dim3(grid_for(h->cap)), dim3(kBlock), 0, h->stream, h->c, h->c.slab_lo + width,
+                     h->c.slab_hi - width, dev_lo ? 1 : 0, dev_hi ? 1 : 0, p.x, p.y, p.z, v.x, v.y, v.z,
+                     h->ids[h->cur_ids], dev_lo, dev_hi, capacity, h->dn + 1);
+  hipLaunchKernelGGL(k_slab_header, dim3(1), dim3(1), 0, h->stream, h->dn + 1, dev_lo, dev_hi, capacity, h->dn + 3);
+  HIP_TRY(h, hipGetLastError());
   return DSL_OK;
 }
 
-int dsl_slab_append(dsl_handle* h, const float* dev_records, int count) {
+int dsl_slab_append(dsl_handle* h, const float* dev_message, int capacity) {
   CHECK_HANDLE(h);
-  if (h->c.slab_axis < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: no slab configured");
-  if (count < 0 || (count > 0 && !dev_records)) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
+  if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: no slab configured");
+  if (!dev_message || capacity < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
   if (!h->forces_uniform) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: forces must be uniform (dsl_reset_forces)");
-  if (h->n + count > h->cap) return fail(h, DSL_ERR_NOMEM, "dsl_slab_append: capacity exceeded");
-  if (count == 0) return DSL_OK;
+  if (capacity == 0) return DSL_OK;
   Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
-  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(count)), dim3(kBlock), 0, h->stream, count, h->n, dev_records, p.x,
-                     p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids]);
+  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(capacity)), dim3(kBlock), 0, h->stream, dev_message, capacity, h->dn,
+                     h->cap, p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], h->dn + 3);
+  hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message, capacity, h->dn, h->cap);
   HIP_TRY(h, hipGetLastError());
-  h->n += count;
-  h->c.n = h->n;
   h->grid_valid = false;
   h->dens_fresh = false;
   return DSL_OK;
@@ -983,13 +1015,15 @@ int dsl_slab_append(dsl_handle* h, const float* dev_records, int count) {
 
 int dsl_get_count(dsl_handle* h, int* n_live, int* n_owned) {
   CHECK_HANDLE(h);
-  if (n_live) *n_live = h->n;
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;
+  if (n_live) *n_live = ncur;
   if (n_owned) {
-    *n_owned = h->n;
-    if (h->c.slab_axis >= 0 && h->n > 0) {
+    *n_owned = ncur;
+    if (h->c.slab_axis >= 0 && ncur > 0) {
       HIP_TRY(h, hipMemsetAsync(h->dcounter, 0, sizeof(int), h->stream));
       CSoa3 p = cpos(h);
-      hipLaunchKernelGGL(k_count_owned, dim3(grid_for(h->n)), dim3(kBlock), 0, h->stream, h->c, p.x, p.y, p.z,
+      hipLaunchKernelGGL(k_count_owned, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, h->c, p.x, p.y, p.z,
                          h->dcounter);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipMemcpyAsync(n_owned, h->dcounter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -999,9 +1033,22 @@ int dsl_get_count(dsl_handle* h, int* n_live, int* n_owned) {
   return DSL_OK;
 }
 
+int dsl_slab_overflow(dsl_handle* h, int* high_water) {
+  CHECK_HANDLE(h);
+  int v = 0;
+  if (h->c.n_ptr) {
+    HIP_TRY(h, hipMemcpyAsync(&v, h->dn + 3, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (high_water) *high_water = v;
+  return DSL_OK;
+}
+
 int dsl_set_ids(dsl_handle* h, const int32_t* ids, size_t count) {
   CHECK_HANDLE(h);
-  if (!ids || count != (size_t)h->n) return fail(h, DSL_ERR_INVALID, "dsl_set_ids: count must equal the particle count");
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;
+  if (!ids || count != (size_t)ncur) return fail(h, DSL_ERR_INVALID, "dsl_set_ids: count must equal the particle count");
   // ids follow the host order of dsl_upload: slot s currently holds host index cur_ids[s]
   std::vector<int> cur(count), out(count);
   HIP_TRY(h, hipMemcpyAsync(cur.data(), h->ids[h->cur_ids], count * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   int cell = -1;
-  if (i < c.n) {
+  const int n = live_n(c);
+  if (i < n) {
     const float x = px[i], y = py[i], z = pz[i];
     cell = cell_of(c, x, y, z);
     if (c.slab_axis >= 0) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   int base = 0;
   if (lane == head_lane && cell >= 0) base = atomicAdd(&cell_count[cell], run);
   base = __shfl(base, head_lane, kWave);
-  if (i < c.n) {
+  if (i < n) {
     cellid[i] = cell;
     rank[i] = base + (lane - head_lane);
   }
@@ -157,11 +158,11 @@ struct ScatterArrays {
   int* ids_dst;
 };
 
-__global__ __launch_bounds__(kBlock) void k_scatter(int n, ScatterArrays a, const int* __restrict__ cellid,
+__global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, const int* __restrict__ cellid,
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
+  if (i >= live_n(c)) return;
   const int d = cell_start[cellid[i]] + rank[i];
   a.ids_dst[d] = a.ids_src[i];
   for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
@@ -209,53 +210,83 @@ __global__ __launch_bounds__(kBlock) void k_pack1(int n, float* __restrict__ sta
 // ---------------------------------------------------------------------------------
 constexpr int kRecord = 7;  // x,y,z,vx,vy,vz,id-bits
 
-__global__ __launch_bounds__(kBlock) void k_slab_pack(DevConsts c, int side, float bound,
-                                                      const float* __restrict__ px, const float* __restrict__ py,
-                                                      const float* __restrict__ pz, const float* __restrict__ vx,
-                                                      const float* __restrict__ vy, const float* __restrict__ vz,
-                                                      const int* __restrict__ ids, float* __restrict__ out,
-                                                      int capacity, int* __restrict__ counter) {
+// Message layout: record 0 is a header whose first word holds the record count (int bits);
+// records 1..count follow.  Both bands are selected in one pass; counters[side] counts.
+__global__ __launch_bounds__(kBlock) void k_slab_pack(DevConsts c, float bound_lo, float bound_hi, int want_lo,
+                                                      int want_hi, const float* __restrict__ px,
+                                                      const float* __restrict__ py, const float* __restrict__ pz,
+                                                      const float* __restrict__ vx, const float* __restrict__ vy,
+                                                      const float* __restrict__ vz, const int* __restrict__ ids,
+                                                      float* __restrict__ out_lo, float* __restrict__ out_hi,
+                                                      int capacity, int* __restrict__ counters) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
-  bool take = false;
+  bool take[2] = {false, false};
   float x = 0.f, y = 0.f, z = 0.f;
-  if (i < c.n) {
+  if (i < live_n(c)) {
     x = px[i];
     y = py[i];
     z = pz[i];
     const float p = c.slab_axis == 0 ? x : (c.slab_axis == 1 ? y : z);
     const bool finite = (x == x) && (y == y) && (z == z);  // ghosts carry NaN after the step
-    take = finite && (side == 0 ? (p < bound) : (p >= bound));
+    take[0] = want_lo && finite && (p < bound_lo);
+    take[1] = want_hi && finite && (p >= bound_hi);
   }
-  const unsigned long long m = __ballot(take);
-  if (m == 0ull) return;
-  const int leader = __builtin_ctzll(m);
-  int base = 0;
-  if (lane == leader) base = atomicAdd(counter, __builtin_popcountll(m));
-  base = __shfl(base, leader, kWave);
-  if (take) {
-    const int d = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-    if (d < capacity) {
-      float* r = out + (size_t)d * kRecord;
-      r[0] = x;
-      r[1] = y;
-      r[2] = z;
-      r[3] = vx[i];
-      r[4] = vy[i];
-      r[5] = vz[i];
-      r[6] = __int_as_float(ids[i]);
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const unsigned long long m = __ballot(take[side]);
+    if (m == 0ull) continue;
+    const int leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&counters[side], __builtin_popcountll(m));
+    base = __shfl(base, leader, kWave);
+    if (take[side]) {
+      const int d = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (d < capacity) {
+        float* r = (side == 0 ? out_lo : out_hi) + (size_t)(d + 1) * kRecord;
+        r[0] = x;
+        r[1] = y;
+        r[2] = z;
+        r[3] = vx[i];
+        r[4] = vy[i];
+        r[5] = vz[i];
+        r[6] = __int_as_float(ids[i]);
+      }
     }
   }
 }
+// header = min(count, capacity); an overflow is recorded for the host to find later
+__global__ void k_slab_header(const int* __restrict__ counters, float* out_lo, float* out_hi, int capacity,
+                              int* __restrict__ overflow) {
+  for (int side = 0; side < 2; ++side) {
+    float* o = side == 0 ? out_lo : out_hi;
+    if (!o) continue;
+    int n = counters[side];
+    if (n > capacity) {
+      atomicMax(overflow, n);
+      n = capacity;
+    }
+    o[0] = __int_as_float(n);
+  }
+}
 
-__global__ __launch_bounds__(kBlock) void k_slab_append(int count, int at, const float* __restrict__ rec,
+// appends the records of a message (count in its header) behind the current particles
+__global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg, int capacity,
+                                                        const int* __restrict__ n_cur, int room,
                                                         float* __restrict__ px, float* __restrict__ py,
                                                         float* __restrict__ pz, float* __restrict__ vx,
                                                         float* __restrict__ vy, float* __restrict__ vz,
-                                                        int* __restrict__ ids) {
+                                                        int* __restrict__ ids, int* __restrict__ overflow) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
+  int count = __float_as_int(msg[0]);
+  count = count < 0 ? 0 : (count > capacity ? capacity : count);
+  const int at = *n_cur;
+  if (at + count > room) {  // does not fit: record it, append nothing
+    if (k == 0) atomicMax(overflow, at + count);
+    return;
+  }
   if (k >= count) return;
-  const float* r = rec + (size_t)k * kRecord;
+  const float* r = msg + (size_t)(k + 1) * kRecord;
   const int d = at + k;
   px[d] = r[0];
   py[d] = r[1];
@@ -265,12 +296,18 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(int count, int at, const
   vz[d] = r[5];
   ids[d] = __float_as_int(r[6]);
 }
+__global__ void k_slab_bump(const float* __restrict__ msg, int capacity, int* __restrict__ n_cur, int room) {
+  int count = __float_as_int(msg[0]);
+  count = count < 0 ? 0 : (count > capacity ? capacity : count);
+  if (*n_cur + count <= room) *n_cur += count;
+}
+__global__ void k_set_count(int* __restrict__ n_cur, const int* __restrict__ src) { *n_cur = *src; }
 
 __global__ __launch_bounds__(kBlock) void k_count_owned(DevConsts c, const float* __restrict__ px,
                                                         const float* __restrict__ py, const float* __restrict__ pz,
                                                         int* __restrict__ counter) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  const bool own = i < c.n && slab_owned(c, px[i], py[i], pz[i]);
+  const bool own = i < live_n(c) && slab_owned(c, px[i], py[i], pz[i]);
   const unsigned long long m = __ballot(own);
   if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(counter, __builtin_popcountll(m));
 }

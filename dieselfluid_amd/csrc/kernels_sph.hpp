@@ -25,7 +25,7 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_density(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
                                                     float* __restrict__ rho, float* __restrict__ pterm) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= c.n) return;
+  if (i >= live_n(c)) return;
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   float density = 0.0f;
   for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
@@ -55,7 +55,7 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_pressure(DevConsts c, const float* __restrict__ rho,
                                                      float* __restrict__ press) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= c.n) return;
+  if (i >= live_n(c)) return;
   press[i] = tait_eos<FAST>(c, rho[i], c.ref_density);
 }
 
@@ -64,7 +64,7 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_pterm(DevConsts c, const float* __restrict__ rho,
                                                   float* __restrict__ pterm) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= c.n) return;
+  if (i >= live_n(c)) return;
   const float d = rho[i];
   pterm[i] = dsl_div<FAST>(tait_eos<FAST>(c, d, c.eos_d0_grad), d * d);
 }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, const int* __r
                                                      Soa3 f, const DevStats* stats, int honour_done) {
   if (honour_done && stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= c.n) return;
+  if (i >= live_n(c)) return;
   float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
   CSoa3 nov{nullptr, nullptr, nullptr};
   force_sweep<FAST, true, false>(c, cell_start, i, p, nov, rho, pterm, accG, accV);
@@ -179,7 +179,7 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, const int* __restrict__ cell_start, CSoa3 p, CSoa3 v,
                                                     const float* __restrict__ rho, Soa3 f) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= c.n) return;
+  if (i >= live_n(c)) return;
   float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
   force_sweep<FAST, false, true>(c, cell_start, i, p, v, rho, nullptr, accG, accV);
   const float tx = accV[0] * c.mu, ty = accV[1] * c.mu, tz = accV[2] * c.mu;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, 
   const int i = blockIdx.x * kBlock + threadIdx.x;
   float fx = c.reset[0], fy = c.reset[1], fz = c.reset[2];
   float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-  const bool live = i < c.n;
+  const bool live = i < live_n(c);
   if (live) {
     if (!forces_uniform) {
       fx = f.x[i];
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const i
                                                             int forces_uniform, Soa3 pout, Soa3 vout,
                                                             DevStats* stats) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  const bool live = i < c.n;
+  const bool live = i < live_n(c);
   const bool owned = live && slab_owned(c, pin.x[i], pin.y[i], pin.z[i]);
   float fx = 0.f, fy = 0.f, fz = 0.f, px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
   if (owned) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, CSoa3 f, So
                                                         const DevStats* stats) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= c.n) return;
+  if (i >= live_n(c)) return;
   const float ax = f.x[i] * c.inv_mass, ay = f.y[i] * c.inv_mass, az = f.z[i] * c.inv_mass;
   const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
   const float tvx = pv.x[i] + dvx, tvy = pv.y[i] + dvy, tvz = pv.z[i] + dvz;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, const int* 
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   unsigned int err_bits = 0u;
-  if (i < c.n) {
+  if (i < live_n(c)) {
     const float xi = pp.x[i], yi = pp.y[i], zi = pp.z[i];
     float density = c.W0;
     for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {

@@ -38,7 +38,12 @@ struct DevConsts {
   // slab ownership (multi-GPU): axis < 0 = everything owned
   int slab_axis;
   float slab_lo, slab_hi;
+  // slab mode keeps the live particle count on the device (no host sync per step);
+  // nullptr = use n
+  const int* n_ptr;
 };
+
+__device__ __forceinline__ int live_n(const DevConsts& c) { return c.n_ptr ? *c.n_ptr : c.n; }
 
 // Host-visible counters living in device memory (fluid.go:25-26, pcisph_darwin.go:46-98).
 struct DevStats {

@@ -92,7 +92,11 @@ class SPHEngine:
         self._ck(self._L.dsl_set_params(self._h, C.byref(p)))
 
     def set_stream(self, stream_ptr):
-        self._ck(self._L.dsl_set_stream(self._h, C.c_void_p(stream_ptr)))
+        """run on the given hipStream_t (0 / None = HIP's default stream)"""
+        self._ck(self._L.dsl_set_stream(self._h, C.c_void_p(stream_ptr or None)))
+
+    def use_own_stream(self):
+        self._ck(self._L.dsl_use_own_stream(self._h))
 
     # -- buffers (ComputeGPU.PassFloatBuffer / ReadFloatBuffer) -------------------
     def upload(self, name: str, arr):
@@ -119,14 +123,17 @@ class SPHEngine:
     def slab_config(self, axis: int, lo: float, hi: float):
         self._ck(self._L.dsl_slab_config(self._h, int(axis), C.c_float(lo), C.c_float(hi)))
 
-    def slab_pack(self, side: int, width: float, dev_ptr: int, capacity: int) -> int:
-        cnt = C.c_int(0)
-        self._ck(self._L.dsl_slab_pack(self._h, int(side), C.c_float(width), C.c_void_p(dev_ptr), int(capacity),
-                                       C.byref(cnt)))
-        return cnt.value
+    def slab_pack(self, width: float, dev_lo: int, dev_hi: int, capacity: int):
+        self._ck(self._L.dsl_slab_pack(self._h, C.c_float(width), C.c_void_p(dev_lo or None),
+                                       C.c_void_p(dev_hi or None), int(capacity)))
 
-    def slab_append(self, dev_ptr: int, count: int):
-        self._ck(self._L.dsl_slab_append(self._h, C.c_void_p(dev_ptr), int(count)))
+    def slab_append(self, dev_msg: int, capacity: int):
+        self._ck(self._L.dsl_slab_append(self._h, C.c_void_p(dev_msg), int(capacity)))
+
+    def slab_overflow(self) -> int:
+        v = C.c_int(0)
+        self._ck(self._L.dsl_slab_overflow(self._h, C.byref(v)))
+        return v.value
 
     def download_ids(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.int32)

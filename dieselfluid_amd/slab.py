@@ -29,31 +29,36 @@ from .engine import SPHEngine
 RECORD = 7  # x,y,z,vx,vy,vz,id-bits
 
 
+def message_count(msg: torch.Tensor) -> int:
+    """record count stored (as int32 bits) in the header record of a message"""
+    return int(msg[0, :1].cpu().contiguous().view(torch.int32).item())
+
+
 class HipSlabEngine:
-    """SPHEngine + device record buffers (torch tensors used as plain device memory)."""
+    """SPHEngine + device message buffers (torch tensors used as plain device memory).
+    A message is (capacity+1) x 7 floats: header record (count) + records."""
 
     def __init__(self, params, device: int, band_capacity: int):
         self.eng = SPHEngine(params, device=device)
         self.dev = torch.device("cuda", device)
         self.band_capacity = int(band_capacity)
-        self._send = [torch.empty((self.band_capacity, RECORD), dtype=torch.float32, device=self.dev)
+        self._send = [torch.zeros((self.band_capacity + 1, RECORD), dtype=torch.float32, device=self.dev)
                       for _ in range(2)]
         # kernels and NCCL ops are ordered through torch's current stream
         self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
 
     # -- protocol -------------------------------------------------------------------
-    def pack(self, side: int, width: float) -> torch.Tensor:
-        buf = self._send[side]
-        cnt = self.eng.slab_pack(side, width, buf.data_ptr(), self.band_capacity)
-        return buf[:cnt]
+    def pack(self, width: float, want_lo: bool, want_hi: bool):
+        """Asynchronous: both band messages are filled on the device, counts included."""
+        self.eng.slab_pack(width, self._send[0].data_ptr() if want_lo else 0,
+                           self._send[1].data_ptr() if want_hi else 0, self.band_capacity)
+        return (self._send[0] if want_lo else None, self._send[1] if want_hi else None)
 
-    def append(self, records: torch.Tensor):
-        if records.shape[0] == 0:
-            return
-        r = records.to(self.dev, dtype=torch.float32).contiguous()
+    def append(self, msg: torch.Tensor):
+        m = msg if msg.device == self.dev else msg.to(self.dev)
         # the engine runs on torch's current stream, so the caching allocator's stream-ordered
-        # reuse keeps r's memory valid until the append kernel has run
-        self.eng.slab_append(r.data_ptr(), r.shape[0])
+        # reuse keeps m's memory valid until the append kernel has run
+        self.eng.slab_append(m.contiguous().data_ptr(), self.band_capacity)
 
     def nn(self):
         self.eng.nn()
@@ -90,48 +95,35 @@ class SlabDriver:
         self.backend = dist.get_backend(group) if world > 1 else "none"
         self.comm_dev = torch.device("cpu") if self.backend != "nccl" else getattr(engine, "dev", torch.device("cuda"))
         self.steps = 0
-        self.last_ghosts = 0
+        self._recv = None
 
     # -- halo + migration exchange ----------------------------------------------------
     def _neighbours(self):
         return (self.rank - 1 if self.rank > 0 else None, self.rank + 1 if self.rank < self.world - 1 else None)
 
     def exchange(self):
+        """One fixed-size message per neighbour and direction; the record count travels in the
+        message header, so nothing here waits for the GPU (with NCCL, Work.wait() only orders
+        the current stream behind the transfer)."""
         if self.world == 1:
             return
         lo_nb, hi_nb = self._neighbours()
-        send = [self.engine.pack(0, self.width) if lo_nb is not None else None,
-                self.engine.pack(1, self.width) if hi_nb is not None else None]
+        send = self.engine.pack(self.width, lo_nb is not None, hi_nb is not None)
         nbs = [lo_nb, hi_nb]
-        # round 1: record counts
-        scnt = [torch.tensor([0 if s is None else s.shape[0]], dtype=torch.int64, device=self.comm_dev) for s in send]
-        rcnt = [torch.zeros(1, dtype=torch.int64, device=self.comm_dev) for _ in range(2)]
+        if self._recv is None:
+            cap = self.engine.band_capacity
+            self._recv = [torch.zeros((cap + 1, RECORD), dtype=torch.float32, device=self.comm_dev) for _ in range(2)]
+        sbuf = [None if s is None else (s if s.device == self.comm_dev else s.to(self.comm_dev)) for s in send]
         ops = []
         for k in range(2):
             if nbs[k] is not None:
-                ops.append(dist.P2POp(dist.isend, scnt[k], nbs[k], group=self.group))
-                ops.append(dist.P2POp(dist.irecv, rcnt[k], nbs[k], group=self.group))
+                ops.append(dist.P2POp(dist.isend, sbuf[k], nbs[k], group=self.group))
+                ops.append(dist.P2POp(dist.irecv, self._recv[k], nbs[k], group=self.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        # round 2: payloads
-        sbuf = [None if s is None else s.to(self.comm_dev).contiguous() for s in send]
-        rbuf = [torch.empty((int(rcnt[k].item()), RECORD), dtype=torch.float32, device=self.comm_dev) for k in range(2)]
-        ops = []
         for k in range(2):
-            if nbs[k] is None:
-                continue
-            if sbuf[k].shape[0] > 0:
-                ops.append(dist.P2POp(dist.isend, sbuf[k], nbs[k], group=self.group))
-            if rbuf[k].shape[0] > 0:
-                ops.append(dist.P2POp(dist.irecv, rbuf[k], nbs[k], group=self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        self.last_ghosts = 0
-        for k in range(2):
-            if nbs[k] is not None and rbuf[k].shape[0] > 0:
-                self.engine.append(rbuf[k])
-                self.last_ghosts += rbuf[k].shape[0]
+            if nbs[k] is not None:
+                self.engine.append(self._recv[k])
 
     def wcsph_step(self, nsteps: int = 1):
         for _ in range(nsteps):

@@ -179,9 +179,11 @@ int dsl_pcisph_step(dsl_handle *h, int nsteps);
 int dsl_get_stats(dsl_handle *h, dsl_stats *out);
 int dsl_sync(dsl_handle *h); /* Queue.Finish() pcisph_gpu_darwin.go:261,271 */
 
-/* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL
- * restores the handle's own stream. */
+/* Run on an existing hipStream_t (e.g. the caller framework's current stream) so that the
+ * caller's copies/collectives and the engine's kernels are ordered.  NULL is HIP's default
+ * stream.  dsl_use_own_stream goes back to the handle's private non-blocking stream. */
 int dsl_set_stream(dsl_handle *h, void *hip_stream);
+int dsl_use_own_stream(dsl_handle *h);
 
 /* Per-kernel device timing with HIP events recorded on the launch stream. */
 int dsl_timing_enable(dsl_handle *h, int on);
@@ -200,22 +202,31 @@ int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
  * (over RCCL, by whatever transport the host owns).  A record is 7 floats:
  * x,y,z,vx,vy,vz and the global particle id as raw int32 bits.
  *
+ * A message is a DEVICE buffer of (capacity+1) records: record 0 is a header whose first word
+ * is the record count (int32 bits), records 1..count follow.  Messages have a fixed size, so
+ * a step needs no host-side counts and no host synchronisation: the live particle count
+ * stays on the device.
+ *
  * dsl_slab_config : this handle owns [lo,hi) along `axis` (use -INFINITY / INFINITY at the
  *                   domain ends); particles outside are ghosts: they take part in the
  *                   neighbour sums but are not integrated and are dropped at the next
  *                   neighbour build.
- * dsl_slab_pack   : copies every owned particle with pos[axis] < lo+width (side 0) or
- *                   >= hi-width (side 1) -- migrants included -- to a DEVICE buffer of
- *                   `capacity` records; *count is the number selected (blocking).
- * dsl_slab_append : appends `count` records from a DEVICE buffer after the current
+ * dsl_slab_pack   : writes every owned particle with pos[axis] < lo+width into dev_lo and
+ *                   every one with pos[axis] >= hi-width into dev_hi (migrants included);
+ *                   either pointer may be NULL.  Asynchronous.
+ * dsl_slab_append : appends the records of a received message behind the current
  *                   particles; they are owned if inside [lo,hi), ghosts otherwise.
+ *                   Asynchronous.
+ * dsl_slab_overflow: largest count that did not fit a message or the particle capacity
+ *                   since creation (0 = none); blocking, for diagnostics.
  * After appending, dsl_build_neighbours drops the previous step's ghosts (the integrate
- * kernels mark them with NaN positions) and updates the live count.  A particle that has
- * just crossed the plane stays one more step as a ghost of its old owner. */
+ * kernels mark them with NaN positions).  A particle that has just crossed the plane stays
+ * one more step as a ghost of its old owner. */
 int dsl_slab_config(dsl_handle *h, int axis, float lo, float hi);
-int dsl_slab_pack(dsl_handle *h, int side, float width, float *dev_records, int capacity, int *count);
-int dsl_slab_append(dsl_handle *h, const float *dev_records, int count);
-int dsl_get_count(dsl_handle *h, int *n_live, int *n_owned);
+int dsl_slab_pack(dsl_handle *h, float width, float *dev_lo, float *dev_hi, int capacity);
+int dsl_slab_append(dsl_handle *h, const float *dev_message, int capacity);
+int dsl_slab_overflow(dsl_handle *h, int *high_water);
+int dsl_get_count(dsl_handle *h, int *n_live, int *n_owned); /* blocking */
 /* global particle ids of the current slots (host order of dsl_upload); default 0..n-1 */
 int dsl_set_ids(dsl_handle *h, const int32_t *ids, size_t count);
 /* Marks every force as equal to force_reset (the state Update leaves, fluid.go:193) */

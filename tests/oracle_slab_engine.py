@@ -52,22 +52,31 @@ class OracleSlabEngine:
             return (pos[:, self.axis] >= self.lo) & (pos[:, self.axis] < self.hi)
 
     # -- protocol ---------------------------------------------------------------------
-    def pack(self, side, width):
+    def _message(self, take):
+        """(capacity+1) x 7 message: header record holds the count as int32 bits"""
+        n = int(take.sum())
+        assert n <= self.band_capacity
+        msg = np.zeros((self.band_capacity + 1, RECORD), np.float32)
+        msg[0, 0] = np.array([n], np.int32).view(np.float32)[0]
+        msg[1:n + 1, 0:3], msg[1:n + 1, 3:6] = self.pos[take], self.vel[take]
+        msg[1:n + 1, 6] = self.ids[take].view(np.float32)
+        return torch.from_numpy(msg)
+
+    def pack(self, width, want_lo, want_hi):
         a = self.pos[:, self.axis]
         finite = np.isfinite(self.pos).all(axis=1)
         with np.errstate(invalid="ignore"):
-            take = finite & ((a < np.float32(self.lo + width)) if side == 0 else (a >= np.float32(self.hi - width)))
-        rec = np.zeros((int(take.sum()), RECORD), np.float32)
-        rec[:, 0:3], rec[:, 3:6] = self.pos[take], self.vel[take]
-        rec[:, 6] = self.ids[take].view(np.float32)
-        assert rec.shape[0] <= self.band_capacity
-        return torch.from_numpy(rec)
+            lo = finite & (a < np.float32(self.lo + width))
+            hi = finite & (a >= np.float32(self.hi - width))
+        return (self._message(lo) if want_lo else None, self._message(hi) if want_hi else None)
 
-    def append(self, records):
-        r = records.cpu().numpy()
-        if r.shape[0] == 0:
+    def append(self, msg):
+        m = msg.cpu().numpy()
+        n = int(m[0, :1].view(np.int32)[0])
+        if n == 0:
             return
-        assert self.pos.shape[0] + r.shape[0] <= self.capacity
+        r = m[1:n + 1]
+        assert self.pos.shape[0] + n <= self.capacity
         self.pos = np.concatenate([self.pos, r[:, 0:3]])
         self.vel = np.concatenate([self.vel, r[:, 3:6]])
         self.ids = np.concatenate([self.ids, np.ascontiguousarray(r[:, 6]).view(np.int32)])

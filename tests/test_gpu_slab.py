@@ -33,7 +33,7 @@ def _worker(rank, world, port, math_mode, out):
     drv.wcsph_step(STEPS)
     res = drv.gather_state(N3 ** 3)
     counts = [None] * world if rank == 0 else None
-    dist.gather_object((drv.engine.n, drv.engine_core.n_owned()), counts, dst=0)
+    dist.gather_object((drv.engine.n, drv.engine_core.n_owned(), drv.engine_core.slab_overflow()), counts, dst=0)
     if rank == 0:
         gp, gv, seen = res
         np.savez(out, pos=gp, vel=gv, seen=seen, counts=np.array(counts))
@@ -48,6 +48,7 @@ def test_two_hip_slabs_match_single_engine(tmp_path, math_mode, tol_x, tol_v):
     z = np.load(out)
     assert np.all(z["seen"] == 1)
     assert z["counts"][:, 0].sum() > N3 ** 3  # ghosts are present on both ranks
+    assert np.all(z["counts"][:, 2] == 0)     # no message / capacity overflow
     p, pos = scenes.dambreak_scene(N3, math_mode=math_mode)
     eng = SPHEngine(p)
     eng.upload("positions", pos)
