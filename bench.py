@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n3", type=int, default=252, help="fluid block edge in particles (252 -> 16.0M)")
     ap.add_argument("--math", choices=["fast", "exact"], default="fast")
+    ap.add_argument("--method", choices=["wcsph", "pcisph"], default="wcsph",
+                    help="pcisph: BASELINE configs[2] style run (use --n3 160 for 4.1M particles); not the bench line")
+    ap.add_argument("--pci-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -101,11 +104,21 @@ def main():
 
     if world == 1:
         p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+        if args.method == "pcisph":
+            # the reference adds the EOS pressure gradient once per correction iteration
+            # (pcisph_darwin.go:93): keep the total impulse of the WCSPH scene
+            p.pci_max_iters = args.pci_iters
+            p.eos_w = p.eos_w / args.pci_iters
+            p.delta = 1.0e-7
         eng = SPHEngine(p, device=local_rank)
         eng.upload("positions", pos)
-        eng.upload("forces", np.tile(np.array(p.force_reset[:], dtype=np.float32), (n_total, 1)))
+        eng.reset_forces()
         del pos
-        step = eng.wcsph_step
+        if args.method == "pcisph":
+            eng.pcisph_begin()
+            step = eng.pcisph_step
+        else:
+            step = eng.wcsph_step
         engines = [eng]
     else:
         from dieselfluid_amd import slab
@@ -138,7 +151,10 @@ def main():
     ms_d, n_d = eng.timing("density")
     ms_f, n_f = eng.timing("force_integrate")
     n_local = eng.n
-    if ms_f >= ms_d:
+    if args.method == "pcisph":
+        ms_f = eng.timing("pci_density")[0]  # dominant PCISPH kernel: predicted density, 20 B/particle
+        kname, kms, kbytes = "k_pci_density", ms_f, 20
+    elif ms_f >= ms_d:
         kname, kms, kbytes = "k_force_integrate", ms_f, BYTES_FORCE
     else:
         kname, kms, kbytes = "k_density", ms_d, BYTES_DENSITY
@@ -171,8 +187,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"WCSPH dam-break, {n_total} particles (n3={n3}), h=2dx, uniform-grid neighbours, "
-                            f"density + pressure/viscosity force + integrate + walls, math={args.math}",
+                "workload": (f"WCSPH dam-break, {n_total} particles (n3={n3}), h=2dx, uniform-grid neighbours, "
+                             f"density + pressure/viscosity force + integrate + walls, math={args.math}")
+                if args.method == "wcsph" else
+                (f"PCISPH dam-break ({args.pci_iters} correction iterations), {n_total} particles (n3={n3}), h=2dx, "
+                 f"uniform-grid neighbours, math={args.math}"),
                 "particles": n_total,
                 "parallelism": "single GPU" if world == 1 else f"{world} spatial slabs + 2h halo",
             },
@@ -191,8 +210,11 @@ def main():
                 "pass_frac_68B": round(n_local * 68 / ((ms_d + ms_f) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if (ms_d + ms_f) > 0 else None,
             },
-            "kernels_ms": {k: round(eng.timing(k)[0], 4) for k in ("cell_rank", "scan", "scatter", "density",
-                                                                     "force_integrate")},
+            "kernels_ms": {k: round(eng.timing(k)[0], 4) for k in
+                           (("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")
+                            if args.method == "wcsph" else
+                            ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
+                             "pci_predict", "pci_density", "update"))},
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,
         }

@@ -49,6 +49,7 @@ struct dsl_handle {
   float* frc[2][3] = {};
   float* pci[2][6] = {};
   float *rho = nullptr, *pterm = nullptr, *press = nullptr, *scratch1 = nullptr;
+  float* gterm[3] = {};  // PCISPH: cached pressure-gradient force term
   int *cellid = nullptr, *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
   float* stage = nullptr;
   DevStats* dstats = nullptr;
@@ -490,6 +491,8 @@ void free_all(dsl_handle* h) {
       (void)hipFree(h->pci[w][k]);
     }
     for (int k = 0; k < 3; ++k) (void)hipFree(h->frc[w][k]);
+    if (w == 0)
+      for (int k = 0; k < 3; ++k) (void)hipFree(h->gterm[k]);
     (void)hipFree(h->ids[w]);
   }
   (void)hipFree(h->rho);
@@ -518,6 +521,8 @@ void free_all(dsl_handle* h) {
 
 int alloc_pci(dsl_handle* h) {
   if (h->pci[0][0]) return DSL_OK;
+  for (int k = 0; k < 3; ++k)
+    if (int rc = dev_alloc(h, &h->gterm[k], (size_t)h->cap)) return rc;
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 6; ++k)
       if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
@@ -924,34 +929,70 @@ int dsl_pcisph_begin(dsl_handle* h) {
 
 int dsl_pcisph_step(dsl_handle* h, int nsteps) {
   CHECK_HANDLE(h);
+  if (h->c.n_ptr) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_pcisph_step: slabs are implemented for the WCSPH step only");
   if (!h->pci_active) {
     if (int rc = dsl_pcisph_begin(h)) return rc;
   }
   const DevConsts& c = h->c;
   dim3 g(grid_for(h->n)), b(kBlock);
+  // FAST mode: LDS-tiled sweeps; the gradient term (a function of x and rho only,
+  // field_types.go:39-42) is identical in every correction iteration, so it is swept once
+  // and re-added.  The running-mass viscosity recurrence for m != 1 needs the branching kernel.
+  const bool tiled = h->prm.math_mode == DSL_MATH_FAST && !(c.visc_running_mass && c.mass != 1.0f);
   for (int s = 0; s < nsteps; ++s) {
     if (int rc = build_grid(h, false)) return rc;
     if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
     if (int rc = materialise_forces(h)) return rc;
     if (int rc = materialise_press(h)) return rc;
-    if (int rc = viscous_pass(h)) return rc;        // ViscousAll  :45
+    CSoa3 p = cpos(h), v = cvel(h);
+    Soa3 F = mfrc(h);
+    CSoa3 cF{F.x, F.y, F.z};
+    if (tiled) {
+      Soa3 G{h->gterm[0], h->gterm[1], h->gterm[2]};
+      Soa3 none{nullptr, nullptr, nullptr};
+      int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45
+        hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                           h->pterm, cF, 0, F, none, h->dstats);
+      });
+      if (rc) return rc;
+      rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
+        hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                           h->pterm, cF, 0, G, none, h->dstats);
+      });
+      if (rc) return rc;
+    } else {
+      if (int rc = viscous_pass(h)) return rc;
+    }
     hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats);
     for (int it = 0; it < h->prm.pci_max_iters; ++it) {
-      CSoa3 p = cpos(h), f = cfrc(h);
       Soa3 pp = mpcip(h), pvv = mpciv(h);
       int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
-        hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, f, pp, pvv, h->dstats);
+        hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, cF, pp, pvv, h->dstats);
       });
       if (rc) return rc;
       CSoa3 cpp{pp.x, pp.y, pp.z};
       rc = timed(h, DSL_K_PCI_DENSITY, [&] {
-        by_math(h, [&](auto fast) {
-          hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, h->cell_start, p, cpp,
-                             h->press, h->dstats);
-        });
+        if (tiled)
+          hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                             h->tiles, h->n_tiles, h->cell_start, p, cpp, h->press, h->dstats);
+        else
+          by_math(h, [&](auto fast) {
+            hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, h->cell_start, p, cpp,
+                               h->press, h->dstats);
+          });
       });
       if (rc) return rc;
-      if ((rc = gradient_pass(h, 1))) return rc;    // GradientPressureForce :93
+      if (tiled) {
+        CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
+        rc = timed(h, DSL_K_GRADIENT, [&] {
+          hipLaunchKernelGGL(k_pci_add_gradient, g, b, 0, h->stream, c, cG, F, h->dstats);
+        });
+        if (rc) return rc;
+      } else if ((rc = gradient_pass(h, 1))) {      // GradientPressureForce :93
+        return rc;
+      }
       hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, c, h->dstats);
     }
     HIP_TRY(h, hipGetLastError());

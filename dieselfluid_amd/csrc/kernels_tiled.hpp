@@ -277,7 +277,13 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
 // ---------------------------------------------------------------------------------
 // [G] [V] X U (tiled): fused WCSPH force + integrate
 // ---------------------------------------------------------------------------------
-template <bool WANT_G, bool WANT_V>
+// OUT selects what happens to the swept sums:
+//   kOutIntegrate  fused WCSPH step: F = reset/forces [+G] [+V] + ext, then Update (pout/vout)
+//   kOutAddForce   the reference's stand-alone passes: forces[pout] += G-term (+ V-term)
+//   kOutStore      pout = G-term (PCISPH: the gradient term is the same in every iteration)
+constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
+
+template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate>
 __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         vx = vin.x[g];
         vy = vin.y[g];
         vz = vin.z[g];
-        owned = slab_owned(c, px, py, pz);
+        owned = OUT != kOutIntegrate || slab_owned(c, px, py, pz);
       }
       if (owned) {
         float gx = 0.f, gy = 0.f, gz = 0.f, lx_ = 0.f, ly_ = 0.f, lz_ = 0.f;
@@ -402,13 +408,15 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
           ly_ = accV[1];
           lz_ = accV[2];
         }
-        fx = c.reset[0];
-        fy = c.reset[1];
-        fz = c.reset[2];
-        if (!forces_uniform) {
-          fx = fin.x[g];
-          fy = fin.y[g];
-          fz = fin.z[g];
+        if constexpr (OUT == kOutIntegrate) {
+          fx = c.reset[0];
+          fy = c.reset[1];
+          fz = c.reset[2];
+          if (!forces_uniform) {
+            fx = fin.x[g];
+            fy = fin.y[g];
+            fz = fin.z[g];
+          }
         }
         if constexpr (WANT_G) {
           const float dm = rho[g] * c.mass * c.pressure_sign;
@@ -421,11 +429,25 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
           fy = __builtin_fmaf(ly_, c.mu, fy);
           fz = __builtin_fmaf(lz_, c.mu, fz);
         }
-        fx += c.ext[0];
-        fy += c.ext[1];
-        fz += c.ext[2];
+        if constexpr (OUT == kOutIntegrate) {
+          fx += c.ext[0];
+          fy += c.ext[1];
+          fz += c.ext[2];
+        }
       } else {
         vx = vy = vz = 0.f;  // not integrated: keep ghosts and idle lanes out of the counters
+      }
+      if constexpr (OUT == kOutAddForce) {
+        pout.x[g] += fx;
+        pout.y[g] += fy;
+        pout.z[g] += fz;
+        continue;
+      }
+      if constexpr (OUT == kOutStore) {
+        pout.x[g] = fx;
+        pout.y[g] = fy;
+        pout.z[g] = fz;
+        continue;
       }
       float npx = px, npy = py, npz = pz, nvx = vx, nvy = vy, nvz = vz;
       integrate_core(c, fx, fy, fz, npx, npy, npz, nvx, nvy, nvz, vbits, fbits);
@@ -447,8 +469,124 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
       }
     }
   }
-  wave_atomic_max(&stats->max_vel_bits, vbits);
-  wave_atomic_max(&stats->max_f_bits, fbits);
+  if constexpr (OUT == kOutIntegrate) {
+    wave_atomic_max(&stats->max_vel_bits, vbits);
+    wave_atomic_max(&stats->max_f_bits, fbits);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// DF (tiled): SPHField.DensityF at the PREDICTED positions (sph_field.go:137-152) +
+// pressure accumulate + max error (pcisph_darwin.go:76-92).  Candidates are the current
+// positions of the staged tile; a target whose predicted position has left the tile interior
+// (the reference never re-synchronises the predictor, so it may) falls back to the
+// global-memory sweep.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
+                                                              const int* __restrict__ n_tiles,
+                                                              const int* __restrict__ cell_start, CSoa3 p, CSoa3 pp,
+                                                              float* __restrict__ press, DevStats* stats) {
+  if (stats->pci_done) return;
+  __shared__ TileMeta m;
+  __shared__ float4 A[kTCap];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+  unsigned int ebits = 0u;
+  TileWalk walk(*n_tiles);
+  int item;
+  while (walk.next(item)) {
+    const int tile = tiles[item];
+    __syncthreads();
+    tile_setup(c, tg, tile, cell_start, m);
+    const bool ovf = m.overflow != 0;
+    const int tx = tile % tg.tnx, ty = (tile / tg.tnx) % tg.tny, tz = tile / (tg.tnx * tg.tny);
+    const float ox = c.gmin[0] + (tx * kTB + 0.5f * kTB) * c.h;
+    const float oy = c.gmin[1] + (ty * kTB + 0.5f * kTB) * c.h;
+    const float oz = c.gmin[2] + (tz * kTB + 0.5f * kTB) * c.h;
+    if (!ovf) {
+      for (int r = wid; r < kTRows; r += kTBlock / kWave) {
+        const int gs = m.row_gs[r], len = m.row_len[r], ls = m.row_lds[r];
+        for (int i = lane; i < len + kTPad; i += kWave) {
+          float4 v = make_float4(kFar, kFar, kFar, 3.0f * kFar * kFar);
+          if (i < len) {
+            const float x = p.x[gs + i] - ox, y = p.y[gs + i] - oy, z = p.z[gs + i] - oz;
+            v = make_float4(x, y, z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+          }
+          A[ls + i] = v;
+        }
+      }
+    }
+    __syncthreads();
+    const int ntarg = m.tprefix[kTB * kTB];
+    const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
+    for (int t = tperm; t < ntarg; t += kTBlock) {
+      int srow, off;
+      tile_target(m, t, srow, off);
+      const int g = m.row_gs[srow] + off;
+      const float qx = pp.x[g], qy = pp.y[g], qz = pp.z[g];
+      // tile-local cell of the predicted position; the LDS image covers it and its 26
+      // neighbours only while it stays inside the tile interior (1..4 per axis)
+      const int lx = cell_coord(qx, c.gmin[0], c.inv_cell, c.dims[0]) - (tx * kTB - 1);
+      const int ly = cell_coord(qy, c.gmin[1], c.inv_cell, c.dims[1]) - (ty * kTB - 1);
+      const int lz = cell_coord(qz, c.gmin[2], c.inv_cell, c.dims[2]) - (tz * kTB - 1);
+      const bool inside = lx >= 1 && lx <= kTB && ly >= 1 && ly <= kTB && lz >= 1 && lz <= kTB;
+      float density;
+      if (!ovf && inside) {
+        const float rx = qx - ox, ry = qy - oy, rz = qz - oz;
+        const float m2x = -2.0f * rx, m2y = -2.0f * ry, m2z = -2.0f * rz;
+        const float ni = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+        const float ninv = -c.inv_hh;
+        float acc = 0.f, acc1 = 0.f;
+        const int qrow = lz * kTH + ly;
+#pragma unroll 1
+        for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+          for (int dy = -1; dy <= 1; ++dy) {
+            const int rr = qrow + dz + dy;
+            const int rb = m.row_lds[rr];
+            int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
+            const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            for (; j < je; j += 4) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float4 cnd = A[j + u];
+                const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
+                const float q = fma_clamp01(r2, ninv, 1.0f);
+                if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+                else acc = __builtin_fmaf(q, q, acc);
+              }
+            }
+          }
+        }
+        density = __builtin_fmaf(acc + acc1, c.mass * c.A, c.W0);  // starts at W0, self included
+      } else {
+        density = c.W0;
+        for_each_candidate(c, cell_start, qx, qy, qz, [&](int j) {
+          const float dx = qx - p.x[j], dy = qy - p.y[j], dz = qz - p.z[j];
+          const float r2 = dist2<true>(dx, dy, dz);
+          if (r2 < c.hh) {
+            const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+            density = __builtin_fmaf(c.mass * c.A, q * q, density);
+          }
+        });
+      }
+      const float density_error = density - c.ref_density;
+      const float abs_err = density_error * __builtin_amdgcn_rcpf(c.ref_density);
+      press[g] += density_error * c.delta;
+      const unsigned int eb = nonneg_bits(abs_err);
+      ebits = eb > ebits ? eb : ebits;
+    }
+  }
+  wave_atomic_max(&stats->pci_cur_err_bits, ebits);
+}
+
+// F += cached gradient term (one per PCISPH correction iteration, pcisph_darwin.go:93)
+__global__ __launch_bounds__(kBlock) void k_pci_add_gradient(DevConsts c, CSoa3 gterm, Soa3 f, const DevStats* stats) {
+  if (stats->pci_done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= live_n(c)) return;
+  f.x[i] += gterm.x[i];
+  f.y[i] += gterm.y[i];
+  f.z[i] += gterm.z[i];
 }
 
 }  // namespace dsl

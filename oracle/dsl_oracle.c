@@ -464,6 +464,7 @@ static dslo_sph *sph_alloc(const dslo_params *prm, int n, const float *hash_vect
   s->kern = dslo_build_kernel(prm->h);                 /* fluid.go:53 */
   /* fluid.go:63: NewParticleArray(num, 0, h, ref_density, mass) */
   dslo_particles_init(&s->parts, n, 0, prm->ref_density, prm->mass);
+  if (prm->d0_override > 0.0f) s->parts.reference_density = prm->d0_override; /* SetReferenceDensity */
   s->particles = n;
   s->cache_life = 0.8f;                                /* fluid.go:19,67 */
   s->mu = prm->mu;                                     /* fluid.go:69 */

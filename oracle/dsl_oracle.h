@@ -110,6 +110,9 @@ typedef struct {
   float restitution;
   /* grid geometry for DSLO_NEIGH_GRID */
   float grid_min[3], grid_max[3];
+  /* > 0: ParticleArray.SetReferenceDensity(d0) after construction (particle_array.go:35-37);
+   * 0: keep NewParticleArray's ReferenceDensity = ref_density * mass (particle_array.go:26) */
+  float d0_override;
 } dslo_params;
 
 /* model/sph/fluid.go:23-33 (+ solver state of pcisph_darwin.go:28-41) */

@@ -76,6 +76,7 @@ class Params(C.Structure):
         ("restitution", C.c_float),
         ("grid_min", C.c_float * 3),
         ("grid_max", C.c_float * 3),
+        ("d0_override", C.c_float),
     ]
 
 

@@ -10,6 +10,9 @@ def oracle_params(p, mode=po.NEIGH_GRID, order=po.ORDER_CELL, n3=0):
     q = po.params_reference(4)
     q.n3 = n3
     q.neigh_mode, q.neigh_order = mode, order
+    # the engine's ref_density is the final D0(); NewParticleArray would multiply by mass again
+    # (particle_array.go:26), so hand it over through SetReferenceDensity (particle_array.go:35-37)
+    q.d0_override = p.ref_density
     for name in ("h", "mass", "ref_density", "mu", "dt", "eos_w", "eos_gamma", "eos_d0_grad", "pressure_sign",
                  "visc_running_mass", "wcsph_pressure_force", "wcsph_viscosity", "pci_max_iters", "pci_max_error",
                  "walls", "restitution"):

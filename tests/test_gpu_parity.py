@@ -179,6 +179,35 @@ def test_pcisph_steps(math_mode, tol):
         eng.close()
 
 
+@pytest.mark.parametrize("math_mode,tol", [(EXACT, 5e-6), (FAST, 1e-4)])
+def test_pcisph_dambreak_scene(math_mode, tol):
+    """PCISPH on the dam-break block (h = 2dx, ~8 particles per cell): in FAST mode this is
+    the LDS-tiled path (tiled viscosity sweep, cached gradient term, tiled DensityF), in
+    EXACT mode the pass-by-pass kernels; both against the oracle's pcisph_darwin.go loop."""
+    from dieselfluid_amd import scenes
+    n3 = 12
+    p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+    p.pci_max_iters = 4
+    p.delta = 2.0e-7
+    vel = helpers.seeded_velocities(n3 ** 3, 0.2)
+    frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (n3 ** 3, 1))
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("velocities", vel)
+    eng.upload("forces", frc)
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel, force=frc)
+    ora.delta = p.delta
+    eng.pcisph_begin(); ora.pcisph_begin()
+    for step in range(3):
+        eng.pcisph_step(1); ora.pcisph_step(1)
+        st = eng.stats()
+        assert st.pci_iters == ora.pci_iters
+        assert abs(st.pci_max_error - ora.pci_error) <= 20 * tol * max(abs(ora.pci_error), 1e-3)
+        assert helpers.rel_err(eng.download("positions"), ora.positions()) < tol
+        assert helpers.rel_err(eng.download("velocities"), ora.velocities(), floor=1e-2) < 20 * tol
+        assert helpers.rel_err(eng.download("pci_positions"), ora.pci_positions()) < tol
+
+
 def test_upload_download_roundtrip_after_sort():
     """P: buffers keep the reference's host order across the device's re-sorting."""
     p, pos, vel = _reference_system(8, EXACT)
