@@ -50,6 +50,8 @@ struct dsl_handle {
   float* pci[2][6] = {};
   float *rho = nullptr, *pterm = nullptr, *press = nullptr, *scratch1 = nullptr;
   float* gterm[3] = {};  // PCISPH: cached pressure-gradient force term
+  unsigned int* nmask = nullptr;  // FAST: per-particle in-range masks from the density sweep (kMaskWords x cap)
+  bool masks_valid = false;
   int *cellid = nullptr, *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
   float* stage = nullptr;
   DevStats* dstats = nullptr;
@@ -240,6 +242,7 @@ int materialise_press(dsl_handle* h) {
 // permutes rho/pterm/press so that an explicit dsl_build_neighbours keeps them usable.
 int build_grid(dsl_handle* h, bool carry_derived) {
   const int n = launch_n(h);
+  h->masks_valid = false;  // slot order changes
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
   HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
@@ -352,10 +355,11 @@ int density_pass(dsl_handle* h) {
   if (h->prm.math_mode == DSL_MATH_FAST) {
     int rc = timed(h, DSL_K_DENSITY, [&] {
       hipLaunchKernelGGL(k_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles,
-                         h->n_tiles, h->cell_start, p, h->rho, h->pterm);
+                         h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap);
     });
     if (rc) return rc;
     h->dens_fresh = true;
+    h->masks_valid = true;  // until positions or the slot order change
     return DSL_OK;
   }
   int rc = timed(h, DSL_K_DENSITY, [&] {
@@ -382,7 +386,8 @@ int force_integrate(dsl_handle* h) {
       dim3 g(persistent_grid(h, 2)), b(kTBlock);
 #define DSL_LAUNCH_FT(GG, VV)                                                                                   \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tiles, h->n_tiles,    \
-                     h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats)
+                     h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats,                         \
+                     h->masks_valid ? h->nmask : nullptr, h->cap)
       if (G && V) DSL_LAUNCH_FT(true, true);
       else if (G) DSL_LAUNCH_FT(true, false);
       else if (V) DSL_LAUNCH_FT(false, true);
@@ -406,6 +411,7 @@ int force_integrate(dsl_handle* h) {
   });
   if (rc) return rc;
   h->cur_pv = o;
+  h->masks_valid = false;    // positions moved
   h->forces_uniform = true;  // Update resets every force to force_reset (fluid.go:193)
   h->press_zero = true;      // ... and every pressure to 0 (fluid.go:192)
   h->grid_valid = false;     // positions moved
@@ -448,6 +454,7 @@ int update_pass(dsl_handle* h) {
   h->forces_uniform = true;
   h->press_zero = true;
   h->grid_valid = false;
+  h->masks_valid = false;
   return DSL_OK;
 }
 
@@ -510,6 +517,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->dn);
   (void)hipFree(h->tiles);
   (void)hipFree(h->n_tiles);
+  (void)hipFree(h->nmask);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (auto& v : h->pending)
     for (auto& pr : v) {
@@ -632,6 +640,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if ((rc = dev_alloc(h, &h->tiles, (size_t)h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 4))) return bail(rc);
+  if (h->prm.math_mode == DSL_MATH_FAST && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
   for (int k = 0; k < 6 && me == hipSuccess; ++k) me = hipMemsetAsync(h->pv[0][k], 0, n * sizeof(float), h->stream);
@@ -726,6 +735,7 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
       Soa3 p = mpos(h, h->cur_pv);
       hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, p.x, p.y, p.z);
       h->grid_valid = false;
+      h->masks_valid = false;
       break;
     }
     case DSL_BUF_VELOCITIES: {
@@ -953,13 +963,13 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
       int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, none, h->dstats);
+                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
       });
       if (rc) return rc;
       rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
         hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, G, none, h->dstats);
+                           h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
       });
       if (rc) return rc;
     } else {

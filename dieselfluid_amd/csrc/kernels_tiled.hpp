@@ -11,6 +11,12 @@
 // candidate loop needs no branch and may over-read into the 4 far-away pad records that
 // end every staged row; that lets it be unrolled by 4 with a single bounds test.
 //
+// Neighbour masks: only ~29 of the 216 swept candidates are within h.  The density pass
+// knows which (q > 0) and emits one 32-bit mask per x-run (9 words per particle, bit order =
+// visit order); the force sweeps then walk only the set bits with the full per-pair
+// arithmetic.  Masks stay valid while positions and slot order do (same step); runs longer
+// than 32 candidates clear the particle's "valid" word and that particle sweeps everything.
+//
 // Work distribution: k_tile_list compacts the non-empty tiles (the dam-break box is ~8x
 // larger than the fluid); a persistent grid walks that list, contiguous chunks per XCD so
 // that neighbouring tiles (which share halo rows) hit the same L2.
@@ -29,6 +35,7 @@ constexpr int kTBlock = 512;           // threads per tile workgroup (8 waves)
 constexpr int kTPad = 4;               // pad records per staged row (over-read guard)
 constexpr int kTCap = 2304;            // staged records per tile (1.33 x the 1728 of 8 per cell)
 constexpr float kFar = 1.0e15f;        // pad coordinate: finite, far outside any domain
+constexpr int kMaskWords = 10;         // 9 run masks + 1 valid word per particle (SoA, stride = capacity)
 
 struct TileMeta {
   int row_gs[kTRows];        // first global slot of the staged row
@@ -177,6 +184,11 @@ __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
   return d;
 }
 
+// mask = 2*mask + (q > 0): compare into VCC, then add-with-carry shifts the bit in
+__device__ __forceinline__ void mask_push(unsigned int& mask, float q) {
+  asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(q) : "vcc");
+}
+
 // ---------------------------------------------------------------------------------
 // D (tiled): densities + P/rho^2
 //
@@ -190,7 +202,8 @@ __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
 __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
                                                           const int* __restrict__ n_tiles,
                                                           const int* __restrict__ cell_start, CSoa3 p,
-                                                          float* __restrict__ rho, float* __restrict__ pterm) {
+                                                          float* __restrict__ rho, float* __restrict__ pterm,
+                                                          unsigned int* __restrict__ nmask, int mstride) {
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
@@ -227,19 +240,24 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       tile_target(m, t, srow, off);
       const int g = m.row_gs[srow] + off;
       float acc = 0.0f, acc1 = 0.0f;
+      unsigned int mvalid = 0u;
       if (!ovf) {
         const float4 me = A[m.row_lds[srow] + off];
         const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
         const float ninv = -c.inv_hh;
         const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+        mvalid = 1u;
+        int ri = 0;
 #pragma unroll 1
         for (int dz = -kTH; dz <= kTH; dz += kTH) {
 #pragma unroll 1
-          for (int dy = -1; dy <= 1; ++dy) {
+          for (int dy = -1; dy <= 1; ++dy, ++ri) {
             const int rr = srow + dz + dy;
             const int rb = m.row_lds[rr];
             int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
             const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            if (je - j > 32) mvalid = 0u;  // more candidates than mask bits: this particle sweeps everything
+            unsigned int mask = 0u;
             for (; j < je; j += 4) {
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
@@ -247,10 +265,12 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
                 // r^2 = |xi|^2 + |xj|^2 - 2 xi.xj ; q = clamp(1 - r^2/h^2)
                 const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
                 const float q = fma_clamp01(r2, ninv, 1.0f);
+                mask_push(mask, q);
                 if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
                 else acc = __builtin_fmaf(q, q, acc);
               }
             }
+            nmask[(size_t)ri * mstride + g] = mask;
           }
         }
         acc = (acc + acc1) - 1.0f;  // the particle met itself once (q = 1)
@@ -268,6 +288,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
         });
       }
       rho[g] = acc;
+      nmask[(size_t)9 * mstride + g] = mvalid;
       const float pr = tait_eos<true>(c, acc, c.eos_d0_grad);
       pterm[g] = dsl_div<true>(pr, acc * acc);
     }
@@ -287,7 +308,8 @@ template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate>
 __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
-    const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats) {
+    const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
+    const unsigned int* __restrict__ nmask, int mstride) {
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];  // x,y,z,P/rho^2
   __shared__ float4 B[kTCap];  // vx,vy,vz,1/rho
@@ -345,39 +367,55 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
             const float ninvh = -c.inv_h;
             float lw_ = 0.f;
             const int lx = cell_coord(px, c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+            // full per-pair arithmetic for candidate record j
+            auto pair = [&](int j) {
+              const float4 a = A[j];
+              const float dx = a.x - px, dyy = a.y - py, dzz = a.z - pz;
+              float r2 = __builtin_fmaf(dzz, dzz, __builtin_fmaf(dyy, dyy, dx * dx));
+              r2 = fmaxf(r2, 1.0e-30f);  // the particle itself: keeps rsq finite, all terms stay 0
+              const float rinv = __builtin_amdgcn_rsqf(r2);
+              const float dist = r2 * rinv;
+              const float q = fma_clamp01(dist, ninvh, 1.0f);
+              if constexpr (WANT_G) {
+                const float k = (q * q) * (pti + a.w) * rinv;
+                gx = __builtin_fmaf(dx, k, gx);
+                gy = __builtin_fmaf(dyy, k, gy);
+                gz = __builtin_fmaf(dzz, k, gz);
+              }
+              if constexpr (WANT_V) {
+                // sum_j (v_j - v_i) w_j = sum_j v_j w_j - v_i sum_j w_j
+                const float4 b = B[j];
+                const float w = q * b.w;
+                lx_ = __builtin_fmaf(b.x, w, lx_);
+                ly_ = __builtin_fmaf(b.y, w, ly_);
+                lz_ = __builtin_fmaf(b.z, w, lz_);
+                lw_ += w;
+              }
+            };
+            const bool masked = nmask != nullptr && nmask[(size_t)9 * mstride + g] != 0u;
+            int ri = 0;
 #pragma unroll 1
             for (int dz = -kTH; dz <= kTH; dz += kTH) {
 #pragma unroll 1
-              for (int dy = -1; dy <= 1; ++dy) {
+              for (int dy = -1; dy <= 1; ++dy, ++ri) {
                 const int rr = srow + dz + dy;
                 const int rb = m.row_lds[rr];
                 int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
                 const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-                for (; j < je; j += 2) {
-#pragma unroll
-                  for (int u = 0; u < 2; ++u) {
-                    const float4 a = A[j + u];
-                    const float dx = a.x - px, dyy = a.y - py, dzz = a.z - pz;
-                    float r2 = __builtin_fmaf(dzz, dzz, __builtin_fmaf(dyy, dyy, dx * dx));
-                    r2 = fmaxf(r2, 1.0e-30f);  // the particle itself: keeps rsq finite, all terms stay 0
-                    const float rinv = __builtin_amdgcn_rsqf(r2);
-                    const float dist = r2 * rinv;
-                    const float q = fma_clamp01(dist, ninvh, 1.0f);
-                    if constexpr (WANT_G) {
-                      const float k = (q * q) * (pti + a.w) * rinv;
-                      gx = __builtin_fmaf(dx, k, gx);
-                      gy = __builtin_fmaf(dyy, k, gy);
-                      gz = __builtin_fmaf(dzz, k, gz);
-                    }
-                    if constexpr (WANT_V) {
-                      // sum_j (v_j - v_i) w_j = sum_j v_j w_j - v_i sum_j w_j
-                      const float4 b = B[j + u];
-                      const float w = q * b.w;
-                      lx_ = __builtin_fmaf(b.x, w, lx_);
-                      ly_ = __builtin_fmaf(b.y, w, ly_);
-                      lz_ = __builtin_fmaf(b.z, w, lz_);
-                      lw_ += w;
-                    }
+                if (masked) {
+                  // walk the in-range bits of this run; bit (K-1-k) <-> candidate k of the run,
+                  // K = run length rounded up to the density sweep's unroll of 4
+                  unsigned int mm = nmask[(size_t)ri * mstride + g];
+                  const int top = j + (((je - j) + 3) & ~3) - 1;
+                  while (mm) {
+                    const int b = __builtin_ctz(mm);
+                    mm &= mm - 1u;
+                    pair(top - b);
+                  }
+                } else {
+                  for (; j < je; j += 2) {
+                    pair(j);
+                    pair(j + 1);
                   }
                 }
               }
