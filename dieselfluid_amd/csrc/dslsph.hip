@@ -671,6 +671,14 @@ int dsl_destroy(dsl_handle* h) {
   if (!h) return DSL_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+#ifdef DSL_DIAG_STAMPS
+  {
+    unsigned long long d[8] = {};
+    (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(dsl::g_diag), sizeof(d));
+    std::fprintf(stderr, "[dsl diag] force kernel, wave-0 clocks: setup %llu staging %llu target-prologue %llu sweep %llu\n",
+                 d[0], d[1], d[2], d[3]);
+  }
+#endif
   free_all(h);
   delete h;
   return DSL_OK;

@@ -50,6 +50,16 @@ struct TileGrid {
   int tnx, tny, tnz, ntiles;
 };
 
+#ifdef DSL_DIAG_STAMPS  // diagnostic build only: per-phase clocks of wave 0 of every block (s_memtime)
+__device__ unsigned long long g_diag[8];
+#define DSL_STAMP(var) const unsigned long long var = clock64()
+#define DSL_STAMP_ADD(slot, a, b) \
+  if (threadIdx.x == 0) atomicAdd(&g_diag[slot], (unsigned long long)((b) - (a)))
+#else
+#define DSL_STAMP(var)
+#define DSL_STAMP_ADD(slot, a, b)
+#endif
+
 // ---------------------------------------------------------------------------------
 // non-empty tile list
 // ---------------------------------------------------------------------------------
@@ -189,6 +199,37 @@ __device__ __forceinline__ void mask_push(unsigned int& mask, float q) {
   asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(q) : "vcc");
 }
 
+// Staging: wave w owns rows w, w+8, ... (at most kRowsPerWave).  The loads of ALL its rows are
+// issued back to back (one record per lane and row) before anything waits, so a tile pays one
+// global-memory latency instead of one per row; rows longer than 64 records finish in a loop.
+constexpr int kRowsPerWave = (kTRows + kTBlock / kWave - 1) / (kTBlock / kWave);  // 5
+
+template <int NF, class Load, class Store>
+__device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane, Load&& load, Store&& store) {
+  float reg[kRowsPerWave][NF];
+  bool have[kRowsPerWave];
+#pragma unroll
+  for (int k = 0; k < kRowsPerWave; ++k) {
+    const int r = wid + k * (kTBlock / kWave);
+    have[k] = r < kTRows && lane < m.row_len[r];
+    if (have[k]) load(m.row_gs[r] + lane, reg[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kRowsPerWave; ++k) {
+    const int r = wid + k * (kTBlock / kWave);
+    if (r >= kTRows) continue;
+    const int len = m.row_len[r], ls = m.row_lds[r];
+    if (lane < len) store(ls + lane, reg[k], true);
+    for (int i = lane + kWave; i < len; i += kWave) {  // rare: more than 64 particles in the row
+      float t[NF];
+      load(m.row_gs[r] + i, t);
+      store(ls + i, t, true);
+    }
+    const int npad = m.row_lds[r + 1] - ls - len;
+    if (lane < npad) store(ls + len + lane, reg[k], false);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // D (tiled): densities + P/rho^2
 //
@@ -219,17 +260,21 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
     const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
-      for (int r = wid; r < kTRows; r += kTBlock / kWave) {
-        const int gs = m.row_gs[r], len = m.row_len[r], ls = m.row_lds[r];
-        for (int i = lane; i < len + kTPad; i += kWave) {
-          float4 v = make_float4(kFar, kFar, kFar, 3.0f * kFar * kFar);
-          if (i < len) {
-            const float x = p.x[gs + i] - ox, y = p.y[gs + i] - oy, z = p.z[gs + i] - oz;
-            v = make_float4(x, y, z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-          }
-          A[ls + i] = v;
-        }
-      }
+      stage_rows<3>(
+          m, wid, lane,
+          [&](int g, float* o) {
+            o[0] = p.x[g];
+            o[1] = p.y[g];
+            o[2] = p.z[g];
+          },
+          [&](int slot, const float* o, bool real) {
+            float4 v = make_float4(kFar, kFar, kFar, 3.0f * kFar * kFar);
+            if (real) {
+              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+              v = make_float4(x, y, z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+            }
+            A[slot] = v;
+          });
     }
     __syncthreads();
     const int ntarg = m.tprefix[kTB * kTB];
@@ -319,30 +364,46 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
   int item;
   while (walk.next(item)) {
     const int tile = tiles[item];
+    DSL_STAMP(t0);
     __syncthreads();
     tile_setup(c, tg, tile, cell_start, m);
+    DSL_STAMP(t1);
+    DSL_STAMP_ADD(0, t0, t1);
     const bool ovf = m.overflow != 0;
     if (!ovf) {
-      for (int r = wid; r < kTRows; r += kTBlock / kWave) {
-        const int gs = m.row_gs[r], len = m.row_len[r], ls = m.row_lds[r];
-        for (int i = lane; i < len + kTPad; i += kWave) {
-          float4 a = make_float4(kFar, kFar, kFar, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i < len) {
-            const int g = gs + i;
-            a = make_float4(pin.x[g], pin.y[g], pin.z[g], WANT_G ? pterm[g] : 0.f);
-            if constexpr (WANT_V) b = make_float4(vin.x[g], vin.y[g], vin.z[g], __builtin_amdgcn_rcpf(rho[g]));
-          }
-          A[ls + i] = a;
-          if constexpr (WANT_V) B[ls + i] = b;
-        }
-      }
+      stage_rows<8>(
+          m, wid, lane,
+          [&](int g, float* o) {
+            o[0] = pin.x[g];
+            o[1] = pin.y[g];
+            o[2] = pin.z[g];
+            o[3] = WANT_G ? pterm[g] : 0.f;
+            if constexpr (WANT_V) {
+              o[4] = vin.x[g];
+              o[5] = vin.y[g];
+              o[6] = vin.z[g];
+              o[7] = rho[g];
+            }
+          },
+          [&](int slot, const float* o, bool real) {
+            float4 a = make_float4(kFar, kFar, kFar, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (real) {
+              a = make_float4(o[0], o[1], o[2], o[3]);
+              if constexpr (WANT_V) b = make_float4(o[4], o[5], o[6], __builtin_amdgcn_rcpf(o[7]));
+            }
+            A[slot] = a;
+            if constexpr (WANT_V) B[slot] = b;
+          });
     }
     __syncthreads();
+    DSL_STAMP(t2);
+    DSL_STAMP_ADD(1, t1, t2);
     const int ntarg = m.tprefix[kTB * kTB];
     const int x0 = (tile % tg.tnx) * kTB - 1;
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     for (int t = tperm; t < ntarg; t += kTBlock) {
       const bool live = true;
+      DSL_STAMP(t3);
       int srow = kTH + 1, off = 0, g = 0;
       if (live) {
         tile_target(m, t, srow, off);
@@ -393,6 +454,8 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
               }
             };
             const bool masked = nmask != nullptr && nmask[(size_t)9 * mstride + g] != 0u;
+            DSL_STAMP(t4);
+            DSL_STAMP_ADD(2, t3, t4);
             int ri = 0;
 #pragma unroll 1
             for (int dz = -kTH; dz <= kTH; dz += kTH) {
@@ -406,6 +469,9 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                   // walk the in-range bits of this run; bit (K-1-k) <-> candidate k of the run,
                   // K = run length rounded up to the density sweep's unroll of 4
                   unsigned int mm = nmask[(size_t)ri * mstride + g];
+#ifdef DSL_DIAG_NO_SWEEP  // timing-only build: measures the per-tile fixed cost (set-up + staging + epilogue)
+                  mm = 0u;
+#endif
                   const int top = j + (((je - j) + 3) & ~3) - 1;
                   while (mm) {
                     const int b = __builtin_ctz(mm);
@@ -420,6 +486,8 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                 }
               }
             }
+            DSL_STAMP(t5);
+            DSL_STAMP_ADD(3, t4, t5);
             if constexpr (WANT_V) {
               lx_ = __builtin_fmaf(-vx, lw_, lx_);
               ly_ = __builtin_fmaf(-vy, lw_, ly_);
