@@ -61,6 +61,8 @@ EXPORTS = {
     "dsl_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "dsl_upload": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
     "dsl_download": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
+    "dsl_download_decimated": (C.c_int, [_vp, C.c_int, C.c_int, _fp, C.c_size_t]),
+    "dsl_device_pointers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
     "dsl_build_neighbours": (C.c_int, [_vp]),
     "dsl_density_pass": (C.c_int, [_vp]),
     "dsl_pressure_pass": (C.c_int, [_vp]),
@@ -69,6 +71,10 @@ EXPORTS = {
     "dsl_gradient_pressure_pass": (C.c_int, [_vp]),
     "dsl_update_pass": (C.c_int, [_vp]),
     "dsl_force_pass": (C.c_int, [_vp]),
+    "dsl_field_divergence": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
+    "dsl_field_curl": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
+    "dsl_field_laplacian": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
+    "dsl_field_interpolate": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t, _fp]),
     "dsl_wcsph_step": (C.c_int, [_vp, C.c_int]),
     "dsl_pcisph_begin": (C.c_int, [_vp]),
     "dsl_pcisph_step": (C.c_int, [_vp, C.c_int]),

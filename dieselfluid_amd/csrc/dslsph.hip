@@ -863,6 +863,40 @@ int dsl_download_cell_start(dsl_handle* h, int32_t* cs, size_t count) {
   return DSL_OK;
 }
 
+int dsl_download_decimated(dsl_handle* h, int buffer, int stride, float* host, size_t count) {
+  CHECK_HANDLE(h);
+  int n = 0;
+  if (int rc = host_count(h, &n)) return rc;
+  if (h->ids_global) return fail(h, DSL_ERR_INVALID, "dsl_download_decimated: host order is gone after dsl_set_ids");
+  if (!host || stride < 1 || (buffer != DSL_BUF_POSITIONS && buffer != DSL_BUF_VELOCITIES))
+    return fail(h, DSL_ERR_INVALID, "dsl_download_decimated: positions or velocities, stride >= 1");
+  const size_t want = 3 * (((size_t)n + stride - 1) / stride);
+  if (count != want) return fail(h, DSL_ERR_INVALID, "dsl_download_decimated: count must be 3*ceil(N/stride)");
+  CSoa3 a = buffer == DSL_BUF_POSITIONS ? cpos(h) : cvel(h);
+  hipLaunchKernelGGL(k_pack3_decimated, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, stride, h->stage,
+                     h->ids[h->cur_ids], a.x, a.y, a.z);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host, h->stage, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+int dsl_device_pointers(dsl_handle* h, int buffer, const float** xyz, const int32_t** ids, int* n) {
+  CHECK_HANDLE(h);
+  if (!xyz || (buffer != DSL_BUF_POSITIONS && buffer != DSL_BUF_VELOCITIES))
+    return fail(h, DSL_ERR_INVALID, "dsl_device_pointers: positions or velocities");
+  int ncur = 0;
+  if (int rc = host_count(h, &ncur)) return rc;  // also drains the stream
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  CSoa3 a = buffer == DSL_BUF_POSITIONS ? cpos(h) : cvel(h);
+  xyz[0] = a.x;
+  xyz[1] = a.y;
+  xyz[2] = a.z;
+  if (ids) *ids = h->ids[h->cur_ids];
+  if (n) *n = ncur;
+  return DSL_OK;
+}
+
 int dsl_build_neighbours(dsl_handle* h) {
   CHECK_HANDLE(h);
   return build_grid(h, true);
@@ -921,6 +955,94 @@ int dsl_force_pass(dsl_handle* h) {
   CHECK_HANDLE(h);
   if (int rc = ensure_grid(h)) return rc;
   return force_integrate(h);
+}
+
+static int field_prepare(dsl_handle* h, int* ncur) {
+  if (h->c.n_ptr) return fail(h, DSL_ERR_UNSUPPORTED, "field operators are not available in slab mode");
+  if (int rc = ensure_grid(h)) return rc;
+  return host_count(h, ncur);
+}
+
+static int field_div_curl(dsl_handle* h, int tensor_buffer, float* host_out, size_t count, bool curl) {
+  CHECK_HANDLE(h);
+  int n = 0;
+  if (int rc = field_prepare(h, &n)) return rc;
+  if (!host_out || count != (size_t)n * (curl ? 3 : 1)) return fail(h, DSL_ERR_INVALID, "field operator: bad output size");
+  CSoa3 t;
+  if (tensor_buffer == DSL_BUF_VELOCITIES) t = cvel(h);
+  else if (tensor_buffer == DSL_BUF_FORCES) {
+    if (int rc = materialise_forces(h)) return rc;
+    t = cfrc(h);
+  } else return fail(h, DSL_ERR_INVALID, "field operator: tensor field must be velocities or forces");
+  CSoa3 p = cpos(h);
+  // results in slot order: x -> scratch1, y/z -> the idle half of the force ping-pong pair
+  Soa3 out{h->scratch1, h->frc[h->cur_f ^ 1][1], h->frc[h->cur_f ^ 1][2]};
+  by_math(h, [&](auto fast) {
+    constexpr bool F = decltype(fast)::value;
+    if (curl)
+      hipLaunchKernelGGL((k_field_div_curl<F, kOpCurl>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
+                         h->cell_start, p, t, h->rho, out);
+    else
+      hipLaunchKernelGGL((k_field_div_curl<F, kOpDiv>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
+                         h->cell_start, p, t, h->rho, out);
+  });
+  HIP_TRY(h, hipGetLastError());
+  const int* ids = h->ids[h->cur_ids];
+  if (curl) hipLaunchKernelGGL(k_pack3, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, h->stage, ids, out.x, out.y, out.z, 0);
+  else hipLaunchKernelGGL(k_pack1, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, h->stage, ids, out.x, 0);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host_out, h->stage, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+int dsl_field_divergence(dsl_handle* h, int tensor_buffer, float* host_out, size_t count) {
+  return field_div_curl(h, tensor_buffer, host_out, count, false);
+}
+int dsl_field_curl(dsl_handle* h, int tensor_buffer, float* host_out, size_t count) {
+  return field_div_curl(h, tensor_buffer, host_out, count, true);
+}
+
+static int scalar_field_id(int buffer) {
+  return buffer == DSL_BUF_DENSITIES ? 0 : (buffer == DSL_BUF_PRESSURES ? 1 : -1);
+}
+
+int dsl_field_laplacian(dsl_handle* h, int scalar_buffer, float* host_out, size_t count) {
+  CHECK_HANDLE(h);
+  int n = 0;
+  if (int rc = field_prepare(h, &n)) return rc;
+  const int field = scalar_field_id(scalar_buffer);
+  if (!host_out || count != (size_t)n || field < 0) return fail(h, DSL_ERR_INVALID, "dsl_field_laplacian: bad argument");
+  CSoa3 p = cpos(h);
+  by_math(h, [&](auto fast) {
+    hipLaunchKernelGGL((k_field_laplacian<decltype(fast)::value>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
+                       h->cell_start, p, h->rho, field, h->scratch1);
+  });
+  hipLaunchKernelGGL(k_pack1, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, h->stage, h->ids[h->cur_ids], h->scratch1, 0);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host_out, h->stage, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+int dsl_field_interpolate(dsl_handle* h, int scalar_buffer, const float* host_positions, size_t npos, float* host_out) {
+  CHECK_HANDLE(h);
+  int n = 0;
+  if (int rc = field_prepare(h, &n)) return rc;
+  const int field = scalar_field_id(scalar_buffer);
+  if (!host_positions || !host_out || field < 0) return fail(h, DSL_ERR_INVALID, "dsl_field_interpolate: bad argument");
+  if (npos > (size_t)h->cap) return fail(h, DSL_ERR_INVALID, "dsl_field_interpolate: at most `capacity` query positions per call");
+  if (npos == 0) return DSL_OK;
+  CSoa3 p = cpos(h);
+  HIP_TRY(h, hipMemcpyAsync(h->stage, host_positions, npos * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  by_math(h, [&](auto fast) {
+    hipLaunchKernelGGL((k_field_interpolate<decltype(fast)::value>), dim3(grid_for((int)npos)), dim3(kBlock), 0, h->stream,
+                       h->c, h->cell_start, p, h->rho, field, (int)npos, h->stage, h->scratch1);
+  });
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host_out, h->scratch1, npos * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
 }
 
 int dsl_wcsph_step(dsl_handle* h, int nsteps) {

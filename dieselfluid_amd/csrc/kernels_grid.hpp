@@ -312,6 +312,20 @@ __global__ __launch_bounds__(kBlock) void k_count_owned(DevConsts c, const float
   if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(counter, __builtin_popcountll(m));
 }
 
+// every stride-th particle (by host index) of a 3-component buffer: out[id/stride] = value(id)
+__global__ __launch_bounds__(kBlock) void k_pack3_decimated(int n, int stride, float* __restrict__ stage,
+                                                            const int* __restrict__ ids, const float* __restrict__ x,
+                                                            const float* __restrict__ y, const float* __restrict__ z) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  const int o = ids[s];
+  if (o % stride != 0) return;
+  const int k = o / stride;
+  stage[3 * k] = x[s];
+  stage[3 * k + 1] = y[s];
+  stage[3 * k + 2] = z[s];
+}
+
 __global__ __launch_bounds__(kBlock) void k_iota(int n, int* __restrict__ ids) {
   const int s = blockIdx.x * kBlock + threadIdx.x;
   if (s < n) ids[s] = s;

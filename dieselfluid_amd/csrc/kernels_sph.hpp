@@ -375,6 +375,107 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const i
 }
 
 // ---------------------------------------------------------------------------------
+// Field operators that no solver calls (model/field/sph_field.go:124-135,203-294):
+// Div, Curl, Laplacian, Interpolate.  Scalar fields: density, or PressureField.Value =
+// TaitEos(rho, 87.0, 0) (field_types.go:39-42); tensor fields: velocity or force.
+// ---------------------------------------------------------------------------------
+enum { kOpDiv = 0, kOpCurl = 1 };
+
+// Div (sph_field.go:203-227) / Curl (:272-294) of a tensor field t
+template <bool FAST, int OP>
+__global__ __launch_bounds__(kBlock) void k_field_div_curl(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+                                                           CSoa3 t, const float* __restrict__ rho, Soa3 out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= live_n(c)) return;
+  const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
+  float div = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+    if (j == i) return;
+    const float dx = p.x[j] - xi, dy = p.y[j] - yi, dz = p.z[j] - zi;
+    const float dist = dsl_sqrt<FAST>(dist2<FAST>(dx, dy, dz));
+    if (!(dist < c.h)) return;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    if (dist != 0.0f) {
+      nx = dsl_div<FAST>(dx, dist);
+      ny = dsl_div<FAST>(dy, dist);
+      nz = dsl_div<FAST>(dz, dist);
+    }
+    const float s = -kern_O1D<FAST>(c, dist);
+    const float gx = nx * s, gy = ny * s, gz = nz * s;
+    const float w = dsl_div<FAST>(c.mass, rho[j]);
+    const float sx = t.x[j] * w, sy = t.y[j] * w, sz = t.z[j] * w;
+    if constexpr (OP == kOpDiv) {
+      const float t0 = sx * gx, t1 = sy * gy, t2 = sz * gz;  // vector.go:268-276 Dot
+      const float d = (t0 + t1) + t2;
+      div += d;
+    } else {
+      const float a0 = sy * gz, b0 = sz * gy;  // vector.go:283-297 Cross
+      const float a1 = sz * gx, b1 = gz * sx;
+      const float a2 = sx * gy, b2 = gx * sy;
+      const float c0 = a0 - b0, c1 = a1 - b1, c2 = a2 - b2;
+      cx = cx + c0;
+      cy = cy + c1;
+      cz = cz + c2;
+    }
+  });
+  if constexpr (OP == kOpDiv) out.x[i] = div;
+  else {
+    out.x[i] = cx;
+    out.y[i] = cy;
+    out.z[i] = cz;
+  }
+}
+
+template <bool FAST>
+__device__ __forceinline__ float scalar_field(const DevConsts& c, int field, const float* __restrict__ rho, int j) {
+  const float d = rho[j];
+  return field == 1 ? tait_eos<FAST>(c, d, c.eos_d0_grad) : d;
+}
+
+// Laplacian (sph_field.go:230-248): sum_j m ((f_j - f_i)/rho_j) O2D(r)
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+                                                            const float* __restrict__ rho, int field,
+                                                            float* __restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= live_n(c)) return;
+  const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
+  const float fi = scalar_field<FAST>(c, field, rho, i);
+  float sum = 0.f;
+  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+    if (j == i) return;
+    const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+    const float dist = dsl_sqrt<FAST>(dist2<FAST>(dx, dy, dz));
+    if (!(dist < c.h)) return;
+    const float df = scalar_field<FAST>(c, field, rho, j) - fi;
+    const float tt = c.mass * dsl_div<FAST>(df, rho[j]);
+    const float u = tt * kern_O2D<FAST>(c, dist);
+    sum += u;
+  });
+  out[i] = sum;
+}
+
+// Interpolate (sph_field.go:124-135) at arbitrary positions q: sum_j (m/rho_j) F(r) f_j
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_field_interpolate(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+                                                              const float* __restrict__ rho, int field, int nq,
+                                                              const float* __restrict__ q, float* __restrict__ out) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nq) return;
+  const float xi = q[3 * k], yi = q[3 * k + 1], zi = q[3 * k + 2];
+  float sum = 0.f;
+  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+    const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+    const float dist = dsl_sqrt<FAST>(dist2<FAST>(dx, dy, dz));
+    if (!(dist < c.h)) return;
+    const float weight = dsl_div<FAST>(c.mass, rho[j]) * kern_F<FAST>(c, dist);
+    const float u = weight * scalar_field<FAST>(c, field, rho, j);
+    sum += u;
+  });
+  out[k] = sum;
+}
+
+// ---------------------------------------------------------------------------------
 // PCISPH (solver/pcisph/pcisph_darwin.go:52-99)
 // ---------------------------------------------------------------------------------
 

@@ -112,6 +112,21 @@ class SPHEngine:
         self._ck(fn(self._h, b, _fp(out), out.size))
         return out.reshape(n, 3) if _COMPS[b] == 3 else out
 
+    def download_decimated(self, name: str, stride: int) -> np.ndarray:
+        """every stride-th particle of positions/velocities (render hand-off)"""
+        n = self.n
+        out = np.empty(3 * ((n + stride - 1) // stride), dtype=np.float32)
+        self._ck(self._L.dsl_download_decimated(self._h, BUF[name], int(stride), _fp(out), out.size))
+        return out.reshape(-1, 3)
+
+    def device_pointers(self, name: str):
+        """(x_ptr, y_ptr, z_ptr), ids_ptr, n of the live SoA device arrays (slot order)"""
+        xyz = (C.c_void_p * 3)()
+        ids = C.c_void_p()
+        n = C.c_int(0)
+        self._ck(self._L.dsl_device_pointers(self._h, BUF[name], xyz, C.byref(ids), C.byref(n)))
+        return (xyz[0], xyz[1], xyz[2]), ids.value, n.value
+
     def set_ids(self, ids):
         a = np.ascontiguousarray(ids, dtype=np.int32)
         self._ck(self._L.dsl_set_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
@@ -171,6 +186,28 @@ class SPHEngine:
 
     def force_pass(self):
         self._ck(self._L.dsl_force_pass(self._h))
+
+    # -- SPHField operators no solver calls (sph_field.go:124-135,203-294) ---------
+    def field_div(self, tensor: str = "velocities") -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float32)
+        self._ck(self._L.dsl_field_divergence(self._h, BUF[tensor], _fp(out), out.size))
+        return out
+
+    def field_curl(self, tensor: str = "velocities") -> np.ndarray:
+        out = np.empty(self.n * 3, dtype=np.float32)
+        self._ck(self._L.dsl_field_curl(self._h, BUF[tensor], _fp(out), out.size))
+        return out.reshape(-1, 3)
+
+    def field_laplacian(self, scalar: str = "densities") -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float32)
+        self._ck(self._L.dsl_field_laplacian(self._h, BUF[scalar], _fp(out), out.size))
+        return out
+
+    def field_interpolate(self, positions, scalar: str = "densities") -> np.ndarray:
+        q = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(q.shape[0], dtype=np.float32)
+        self._ck(self._L.dsl_field_interpolate(self._h, BUF[scalar], _fp(q), q.shape[0], _fp(out)))
+        return out
 
     # -- solver drivers -----------------------------------------------------------
     def wcsph_step(self, nsteps: int = 1):

@@ -154,6 +154,17 @@ int dsl_get_params(dsl_handle *h, dsl_params *out);
 int dsl_upload(dsl_handle *h, int buffer, const float *host, size_t count);
 int dsl_download(dsl_handle *h, int buffer, float *host, size_t count);
 
+/* Render hand-off without the per-step full read-back of pcisph_gpu_darwin.go:276-277
+ * (SURVEY 8f rank 1):
+ * dsl_download_decimated: every stride-th particle (host index 0, stride, 2*stride, ...) of a
+ *   3-component buffer, count = 3*ceil(N/stride) floats; blocking.
+ * dsl_device_pointers: the live device arrays themselves (SoA, cell-sorted slot order) for a
+ *   consumer that can read device memory (another HIP kernel, graphics interop):
+ *   xyz[3] component pointers of `buffer`, ids = slot -> particle index, n = slot count.
+ *   Valid until the next call that steps, uploads or rebuilds the neighbour table. */
+int dsl_download_decimated(dsl_handle *h, int buffer, int stride, float *host, size_t count);
+int dsl_device_pointers(dsl_handle *h, int buffer, const float **xyz, const int32_t **ids, int *n);
+
 /* SPH.NN() / HashSampler.UpdateSampler (fluid.go:100-102, sampler/lsh/lsh.go:126-133):
  * rebuilds the neighbour table (cell hash, histogram, prefix sum, counting-sort scatter). */
 int dsl_build_neighbours(dsl_handle *h);
@@ -168,6 +179,17 @@ int dsl_update_pass(dsl_handle *h);                   /* Update                :
 /* Fused form of [GradientPressureForce][ViscousAll] ExternalAll PressureAll Update used by
  * dsl_wcsph_step; needs densities from dsl_density_pass. */
 int dsl_force_pass(dsl_handle *h);
+
+/* The SPHField operators no solver calls (model/field/sph_field.go), evaluated on the current
+ * state (densities as left by the last dsl_density_pass).  tensor_buffer is
+ * DSL_BUF_VELOCITIES or DSL_BUF_FORCES; scalar_buffer is DSL_BUF_DENSITIES (DensityField) or
+ * DSL_BUF_PRESSURES (PressureField.Value = TaitEos(rho, 87.0, 0), field_types.go:39-42).
+ * Results come back in host order; blocking. */
+int dsl_field_divergence(dsl_handle *h, int tensor_buffer, float *host_out, size_t count);   /* Div         :203-227, N   */
+int dsl_field_curl(dsl_handle *h, int tensor_buffer, float *host_out, size_t count);         /* Curl        :272-294, 3N  */
+int dsl_field_laplacian(dsl_handle *h, int scalar_buffer, float *host_out, size_t count);    /* Laplacian   :230-248, N   */
+int dsl_field_interpolate(dsl_handle *h, int scalar_buffer, const float *host_positions,     /* Interpolate :124-135      */
+                          size_t n_positions, float *host_out);
 
 /* Step drivers: one iteration of WCSPH.Run (solver/wcsph/wcsph.go:14-26) and of
  * PciMethod.Run (solver/pcisph/pcisph_darwin.go:43-101) per step.  Asynchronous: they

@@ -656,6 +656,104 @@ static void field_laplacian_force(dslo_sph *s, int i, float out[3]) {
   for (int a = 0; a < 3; a++) out[a] = force[a];
 }
 
+/* ---- the field operators no solver calls ------------------------------
+ * scalar fields: 0 = DensityField.Value (field_types.go:17-19), 1 = PressureField.Value
+ * (TaitEos(rho, 87.0, 0), field_types.go:39-42); tensor fields: 0 = velocity, 1 = force. */
+static float scalar_field_value(const dslo_sph *s, int field, int i) {
+  if (field == 1) return pressure_field_value(s, i);
+  return dslo_particles_get(&s->parts, i).density;
+}
+static void tensor_field_value(const dslo_sph *s, int field, int i, float out[3]) {
+  dslo_particle q = dslo_particles_get(&s->parts, i);
+  memcpy(out, field == 1 ? q.force : q.velocity, 3 * sizeof(float));
+}
+
+/* sph_field.go:203-227 Div */
+float dslo_field_div(dslo_sph *s, int i, int tensor_field) {
+  dslo_particle pi = dslo_particles_get(&s->parts, i);
+  const int *samples;
+  int len = dslo_get_samples(s, i, &samples);
+  float div = 0.0f, mass = s->parts.mass;
+  for (int j = 0; j < len; j++) {
+    int jIndex = samples[j];
+    if (jIndex != i) {
+      dslo_particle q = dslo_particles_get(&s->parts, jIndex);
+      float dir[3], nd[3], grad[3], fv[3], sv[3];
+      vsub3(q.position, pi.position, dir);
+      float dist = dslo_vec_mag(dir, 3);
+      if (!in_support(s, dist)) continue;
+      dslo_vec_norm3(dir, nd);
+      dslo_kernel_grad(&s->kern, dist, nd, grad);
+      tensor_field_value(s, tensor_field, jIndex, fv);
+      float w = mass / q.density;
+      for (int a = 0; a < 3; a++) sv[a] = fv[a] * w;
+      div += dslo_vec_dot3(sv, grad);
+    }
+  }
+  return div;
+}
+
+/* sph_field.go:272-294 Curl */
+void dslo_field_curl(dslo_sph *s, int i, int tensor_field, float out[3]) {
+  dslo_particle pi = dslo_particles_get(&s->parts, i);
+  const int *samples;
+  int len = dslo_get_samples(s, i, &samples);
+  float curl[3] = {0.0f, 0.0f, 0.0f}, mass = s->parts.mass;
+  for (int j = 0; j < len; j++) {
+    int jIndex = samples[j];
+    if (jIndex != i) {
+      dslo_particle q = dslo_particles_get(&s->parts, jIndex);
+      float dir[3], nd[3], grad[3], fv[3], sv[3], c[3];
+      vsub3(q.position, pi.position, dir);
+      float dist = dslo_vec_mag(dir, 3);
+      if (!in_support(s, dist)) continue;
+      dslo_vec_norm3(dir, nd);
+      dslo_kernel_grad(&s->kern, dist, nd, grad);
+      tensor_field_value(s, tensor_field, jIndex, fv);
+      float w = mass / q.density;
+      for (int a = 0; a < 3; a++) sv[a] = fv[a] * w;
+      dslo_vec_cross3(sv, grad, c);
+      for (int a = 0; a < 3; a++) curl[a] = curl[a] + c[a];
+    }
+  }
+  memcpy(out, curl, sizeof(curl));
+}
+
+/* sph_field.go:230-248 Laplacian */
+float dslo_field_laplacian(dslo_sph *s, int i, int scalar_field) {
+  dslo_particle pi = dslo_particles_get(&s->parts, i);
+  const int *samples;
+  int len = dslo_get_samples(s, i, &samples);
+  float m = s->parts.mass, sum = 0.0f;
+  for (int j = 0; j < len; j++) {
+    int jIndex = samples[j];
+    dslo_particle q = dslo_particles_get(&s->parts, jIndex);
+    if (jIndex != i) {
+      float dist = dslo_vec_dist3(pi.position, q.position);
+      if (!in_support(s, dist)) continue;
+      float df = scalar_field_value(s, scalar_field, jIndex) - scalar_field_value(s, scalar_field, i);
+      float t = m * (df / q.density);
+      sum += t * dslo_kernel_O2D(&s->kern, dist);
+    }
+  }
+  return sum;
+}
+
+/* sph_field.go:124-135 Interpolate */
+float dslo_field_interpolate(dslo_sph *s, const float pos[3], int scalar_field) {
+  const int *samples;
+  int len = dslo_get_samples_from_position(s, pos, &samples);
+  float sum = 0.0f, mass = s->parts.mass;
+  for (int k = 0; k < len; k++) {
+    dslo_particle q = dslo_particles_get(&s->parts, samples[k]);
+    float dist = dslo_vec_dist3(pos, q.position);
+    if (!in_support(s, dist)) continue;
+    float weight = mass / q.density * dslo_kernel_F(&s->kern, dist);
+    sum += weight * scalar_field_value(s, scalar_field, samples[k]);
+  }
+  return sum;
+}
+
 /* =====================================================================================
  * passes: model/sph/fluid.go
  * ===================================================================================== */

@@ -190,6 +190,12 @@ float dslo_cache_incr(dslo_sph *s, int *rebuilt);
 float dslo_pcidelta(dslo_sph *s);
 float dslo_density_f(dslo_sph *s, const float pos[3]);
 
+/* ---- unused-by-solvers field operators: model/field/sph_field.go:124-135,203-294 ---- */
+float dslo_field_div(dslo_sph *s, int i, int tensor_field);
+void dslo_field_curl(dslo_sph *s, int i, int tensor_field, float out[3]);
+float dslo_field_laplacian(dslo_sph *s, int i, int scalar_field);
+float dslo_field_interpolate(dslo_sph *s, const float pos[3], int scalar_field);
+
 /* ---- drivers: solver/wcsph/wcsph.go:14-26, solver/pcisph/pcisph_darwin.go:24-118 -- */
 void dslo_wcsph_step(dslo_sph *s);
 void dslo_pcisph_begin(dslo_sph *s);

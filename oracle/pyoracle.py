@@ -152,6 +152,10 @@ def lib() -> C.CDLL:
         "dslo_field_gradient": (None, [vp, C.c_int, fp]),
         "dslo_field_laplacian_force": (None, [vp, C.c_int, fp]),
         "dslo_lsh_hash_pos": (C.c_int, [vp, fp]),
+        "dslo_field_div": (C.c_float, [vp, C.c_int, C.c_int]),
+        "dslo_field_curl": (None, [vp, C.c_int, C.c_int, fp]),
+        "dslo_field_laplacian": (C.c_float, [vp, C.c_int, C.c_int]),
+        "dslo_field_interpolate": (C.c_float, [vp, fp, C.c_int]),
     }
     for name, s in sig.items():
         if s is None:
@@ -373,6 +377,33 @@ class OracleSPH:
         out = np.zeros(3, dtype=np.float32)
         self._L.dslo_field_laplacian_force(self._h, int(i), _fp(out))
         return out
+
+    # -- field operators no solver calls (sph_field.go:124-135,203-294) -----------------
+    SCALAR = {"density": 0, "pressure": 1}
+    TENSOR = {"velocity": 0, "force": 1}
+
+    def field_div(self, tensor="velocity"):
+        f = self.TENSOR[tensor]
+        return np.array([self._L.dslo_field_div(self._h, i, f) for i in range(self.n)], dtype=np.float32)
+
+    def field_curl(self, tensor="velocity"):
+        f = self.TENSOR[tensor]
+        out = np.zeros((self.n, 3), dtype=np.float32)
+        tmp = np.zeros(3, dtype=np.float32)
+        for i in range(self.n):
+            self._L.dslo_field_curl(self._h, i, f, _fp(tmp))
+            out[i] = tmp
+        return out
+
+    def field_laplacian(self, scalar="density"):
+        f = self.SCALAR[scalar]
+        return np.array([self._L.dslo_field_laplacian(self._h, i, f) for i in range(self.n)], dtype=np.float32)
+
+    def field_interpolate(self, positions, scalar="density"):
+        f = self.SCALAR[scalar]
+        pos = f32(positions).reshape(-1, 3)
+        return np.array([self._L.dslo_field_interpolate(self._h, _fp(pos[k]), f) for k in range(pos.shape[0])],
+                        dtype=np.float32)
 
     # -- drivers --------------------------------------------------------------------
     def wcsph_step(self, nsteps=1):

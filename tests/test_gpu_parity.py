@@ -208,6 +208,30 @@ def test_pcisph_dambreak_scene(math_mode, tol):
         assert helpers.rel_err(eng.download("pci_positions"), ora.pci_positions()) < tol
 
 
+@pytest.mark.parametrize("math_mode,tol", [(EXACT, 5e-6), (FAST, 5e-5)])
+def test_field_operators(math_mode, tol):
+    """Div, Curl, Laplacian, Interpolate (sph_field.go:124-135,203-294)."""
+    p, pos, vel = _reference_system(12, math_mode)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("velocities", vel)
+    eng.density_all()
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel)
+    ora.density_all()
+    assert helpers.rel_err(eng.field_div("velocities"), ora.field_div("velocity")) < tol
+    assert helpers.rel_err(eng.field_curl("velocities"), ora.field_curl("velocity")) < tol
+    assert helpers.rel_err(eng.field_laplacian("densities"), ora.field_laplacian("density")) < tol
+    assert helpers.rel_err(eng.field_laplacian("pressures"), ora.field_laplacian("pressure")) < 8 * tol
+    q = (pos[::7] * np.float32(0.93) + np.float32(0.01)).astype(np.float32)
+    assert helpers.rel_err(eng.field_interpolate(q, "densities"), ora.field_interpolate(q, "density")) < tol
+    assert helpers.rel_err(eng.field_interpolate(q, "pressures"), ora.field_interpolate(q, "pressure")) < 8 * tol
+    # a tensor field other than velocity: forces after ExternalAll + ViscousAll
+    g = np.array([0, -9.81, 0], dtype=np.float32)
+    eng.external_all(g); ora.external_all(g)
+    eng.viscous_all(); ora.viscous_all()
+    assert helpers.rel_err(eng.field_div("forces"), ora.field_div("force")) < 2 * tol
+
+
 def test_upload_download_roundtrip_after_sort():
     """P: buffers keep the reference's host order across the device's re-sorting."""
     p, pos, vel = _reference_system(8, EXACT)
@@ -220,6 +244,29 @@ def test_upload_download_roundtrip_after_sort():
     vel2 = (vel * np.float32(2)).astype(np.float32)
     eng.upload("velocities", vel2)  # upload while the device order is permuted
     assert np.array_equal(eng.download("velocities"), vel2)
+
+
+def test_render_handoff_decimated_and_device_pointers():
+    """positions for the renderer without the full per-step read-back."""
+    import ctypes as C
+    import torch
+    p, pos, vel = _reference_system(8, EXACT)
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("velocities", vel)
+    eng.nn()
+    for stride in (1, 3, 8):
+        assert np.array_equal(eng.download_decimated("positions", stride), pos[::stride])
+        assert np.array_equal(eng.download_decimated("velocities", stride), vel[::stride])
+    (xp, yp, zp), idp, n = eng.device_pointers("positions")
+    assert n == eng.n and xp and yp and zp and idp
+    # read the device arrays through HIP without going through the library
+    hip = C.CDLL("libamdhip64.so")
+    x = np.empty(n, dtype=np.float32)
+    ids = np.empty(n, dtype=np.int32)
+    assert hip.hipMemcpy(x.ctypes.data_as(C.c_void_p), C.c_void_p(xp), C.c_size_t(4 * n), 2) == 0
+    assert hip.hipMemcpy(ids.ctypes.data_as(C.c_void_p), C.c_void_p(idp), C.c_size_t(4 * n), 2) == 0
+    assert np.array_equal(x, pos[ids, 0])
 
 
 def test_error_paths_do_not_abort():
