@@ -63,6 +63,8 @@ EXPORTS = {
     "dsl_download": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
     "dsl_download_decimated": (C.c_int, [_vp, C.c_int, C.c_int, _fp, C.c_size_t]),
     "dsl_device_pointers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
+    "dsl_set_hash_vectors": (C.c_int, [_vp, _fp, C.c_int]),
+    "dsl_lsh_download_table": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_build_neighbours": (C.c_int, [_vp]),
     "dsl_density_pass": (C.c_int, [_vp]),
     "dsl_pressure_pass": (C.c_int, [_vp]),

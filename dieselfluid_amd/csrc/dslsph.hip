@@ -24,6 +24,7 @@
 #include <utility>
 #include <vector>
 
+#include "kernels_lsh.hpp"
 #include "kernels_tiled.hpp"
 
 using namespace dsl;
@@ -41,6 +42,11 @@ struct dsl_handle {
   bool ids_global = false;  // dsl_set_ids replaced the host-order map
   int* dcounter = nullptr;
   int* dn = nullptr;  // slab mode: [0] live particle count, [1],[2] band counters, [3] overflow high-water mark
+  // DSL_NEIGH_LSH_REF
+  bool lsh = false;
+  int lsh_bits = 0, lsh_cap = 0;
+  float* hashv = nullptr;
+  int *bucket_of = nullptr, *lsh_table = nullptr, *lsh_len = nullptr, *lsh_samples = nullptr;
   TileGrid tg{};
   int *tiles = nullptr, *n_tiles = nullptr;
   // SoA state
@@ -102,7 +108,11 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   if (p.n_particles <= 0) return fail(h, DSL_ERR_INVALID, "n_particles must be > 0");
   if (p.n_boundary != 0)
     return fail(h, DSL_ERR_UNSUPPORTED, "boundary particles are not supported (disabled in the reference, fluid.go:70)");
-  if (p.neigh_mode != DSL_NEIGH_GRID) return fail(h, DSL_ERR_UNSUPPORTED, "neigh_mode must be DSL_NEIGH_GRID");
+  if (p.neigh_mode != DSL_NEIGH_GRID && p.neigh_mode != DSL_NEIGH_LSH_REF) return fail(h, DSL_ERR_INVALID, "bad neigh_mode");
+  if (p.neigh_mode == DSL_NEIGH_LSH_REF && p.math_mode != DSL_MATH_EXACT)
+    return fail(h, DSL_ERR_UNSUPPORTED, "DSL_NEIGH_LSH_REF is a parity mode: it needs DSL_MATH_EXACT");
+  if (p.neigh_mode == DSL_NEIGH_LSH_REF && (p.lsh_buckets < 1 || p.lsh_buckets > 4096))
+    return fail(h, DSL_ERR_INVALID, "lsh_buckets out of range");
   if (p.math_mode != DSL_MATH_EXACT && p.math_mode != DSL_MATH_FAST) return fail(h, DSL_ERR_INVALID, "bad math_mode");
   c.n = p.n_particles;
   const float hh = p.h;
@@ -220,6 +230,11 @@ CSoa3 cfrc(dsl_handle* h) { return {h->frc[h->cur_f][0], h->frc[h->cur_f][1], h-
 Soa3 mpcip(dsl_handle* h) { return {h->pci[h->cur_pci][0], h->pci[h->cur_pci][1], h->pci[h->cur_pci][2]}; }
 Soa3 mpciv(dsl_handle* h) { return {h->pci[h->cur_pci][3], h->pci[h->cur_pci][4], h->pci[h->cur_pci][5]}; }
 
+Neigh neigh(const dsl_handle* h) {
+  if (h->lsh) return Neigh{h->cell_start, h->lsh_samples, h->hashv, h->lsh_bits, h->prm.lsh_buckets};
+  return Neigh{h->cell_start, nullptr, nullptr, 0, 0};
+}
+
 // forces are kept implicit (== force_reset) after Update until a pass needs the array
 int materialise_forces(dsl_handle* h) {
   if (!h->forces_uniform) return DSL_OK;
@@ -240,7 +255,26 @@ int materialise_press(dsl_handle* h) {
 
 // cell hash -> histogram -> prefix sum -> counting-sort scatter.  carry_derived also
 // permutes rho/pterm/press so that an explicit dsl_build_neighbours keeps them usable.
+// HashSampler.UpdateSampler on the device: nothing is re-ordered, slots stay in host order
+int build_lsh(dsl_handle* h) {
+  const int n = h->n;
+  CSoa3 p = cpos(h);
+  Neigh nb = neigh(h);
+  const int B = h->prm.lsh_buckets;
+  int rc = timed(h, DSL_K_CELL_RANK, [&] {
+    hipLaunchKernelGGL(k_lsh_bucket, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, nb, p.x, p.y, p.z, h->bucket_of);
+    hipLaunchKernelGGL(k_lsh_table, dim3(B), dim3(kWave), 0, h->stream, n, h->bucket_of, h->lsh_cap, h->lsh_table,
+                       h->lsh_len);
+    hipLaunchKernelGGL(k_lsh_samples, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, h->lsh_cap, h->lsh_table,
+                       h->lsh_len, h->lsh_samples);
+  });
+  if (rc) return rc;
+  h->grid_valid = true;
+  return DSL_OK;
+}
+
 int build_grid(dsl_handle* h, bool carry_derived) {
+  if (h->lsh) return build_lsh(h);
   const int n = launch_n(h);
   h->masks_valid = false;  // slot order changes
   const DevConsts& c = h->c;
@@ -338,7 +372,7 @@ int by_math(dsl_handle* h, Launch&& l) {
 // (sph_field.go:265) is order- and membership-dependent for m != 1 and stays on the
 // branching lane-per-particle kernel.
 bool use_tiled(const dsl_handle* h) {
-  if (h->prm.math_mode != DSL_MATH_FAST) return false;
+  if (h->prm.math_mode != DSL_MATH_FAST || h->lsh) return false;
   if (h->c.wcsph_viscosity && h->c.visc_running_mass && h->c.mass != 1.0f) return false;
   return true;
 }
@@ -365,7 +399,7 @@ int density_pass(dsl_handle* h) {
   int rc = timed(h, DSL_K_DENSITY, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         h->cell_start, p, h->rho, h->pterm);
+                         neigh(h), p, h->rho, h->pterm);
     });
   });
   if (rc) return rc;
@@ -400,7 +434,7 @@ int force_integrate(dsl_handle* h) {
       constexpr bool FAST = decltype(fast)::value;
       dim3 g(grid_for(launch_n(h))), b(kBlock);
 #define DSL_LAUNCH_FI(GG, VV)                                                                                    \
-  hipLaunchKernelGGL((k_force_integrate<FAST, GG, VV>), g, b, 0, h->stream, c, h->cell_start, p, v, h->rho,     \
+  hipLaunchKernelGGL((k_force_integrate<FAST, GG, VV>), g, b, 0, h->stream, c, neigh(h), p, v, h->rho,          \
                      h->pterm, f, uni, po, vo, h->dstats)
       if (G && V) DSL_LAUNCH_FI(true, true);
       else if (G) DSL_LAUNCH_FI(true, false);
@@ -425,7 +459,7 @@ int gradient_pass(dsl_handle* h, int honour_done) {
   return timed(h, DSL_K_GRADIENT, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_gradient<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         h->cell_start, p, h->rho, h->pterm, f, h->dstats, honour_done);
+                         neigh(h), p, h->rho, h->pterm, f, h->dstats, honour_done);
     });
   });
 }
@@ -437,7 +471,7 @@ int viscous_pass(dsl_handle* h) {
   return timed(h, DSL_K_VISCOUS, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_viscous<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         h->cell_start, p, v, h->rho, f);
+                         neigh(h), p, v, h->rho, f);
     });
   });
 }
@@ -517,6 +551,11 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->dn);
   (void)hipFree(h->tiles);
   (void)hipFree(h->n_tiles);
+  (void)hipFree(h->hashv);
+  (void)hipFree(h->bucket_of);
+  (void)hipFree(h->lsh_table);
+  (void)hipFree(h->lsh_len);
+  (void)hipFree(h->lsh_samples);
   (void)hipFree(h->nmask);
   for (hipEvent_t e : h->pool) (void)hipEventDestroy(e);
   for (auto& v : h->pending)
@@ -635,6 +674,21 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
       (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 4)))
     return bail(rc);
+  h->lsh = params->neigh_mode == DSL_NEIGH_LSH_REF;
+  if (h->lsh) {
+    const int B = params->lsh_buckets;
+    h->lsh_cap = params->lsh_bucket_size > kLshSamples ? params->lsh_bucket_size : kLshSamples;
+    h->lsh_bits = 8;  // lsh.Allocate(num, 255, 8, ..) fluid.go:64
+    if ((rc = dev_alloc(h, &h->hashv, 32 * 3)) || (rc = dev_alloc(h, &h->bucket_of, n)) ||
+        (rc = dev_alloc(h, &h->lsh_table, (size_t)B * h->lsh_cap)) || (rc = dev_alloc(h, &h->lsh_len, (size_t)B)) ||
+        (rc = dev_alloc(h, &h->lsh_samples, (size_t)B * kLshSamples)))
+      return bail(rc);
+    if (hipMemsetAsync(h->hashv, 0, 32 * 3 * sizeof(float), h->stream) != hipSuccess ||
+        hipMemsetAsync(h->lsh_table, 0, (size_t)B * h->lsh_cap * sizeof(int), h->stream) != hipSuccess) {
+      h->err = "hipMemsetAsync failed";
+      return bail(DSL_ERR_DEVICE);
+    }
+  }
   h->tg.tnx = (h->c.dims[0] + kTB - 1) / kTB;
   h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
@@ -857,7 +911,7 @@ int dsl_download_ids(dsl_handle* h, int32_t* ids, size_t count) {
 int dsl_download_cell_start(dsl_handle* h, int32_t* cs, size_t count) {
   CHECK_HANDLE(h);
   if (!cs || count != (size_t)h->ncell + 1) return fail(h, DSL_ERR_INVALID, "dsl_download_cell_start: count must be cells+1");
-  if (!h->grid_valid) return fail(h, DSL_ERR_INVALID, "dsl_download_cell_start: neighbour table is stale");
+  if (!h->grid_valid || h->lsh) return fail(h, DSL_ERR_INVALID, "dsl_download_cell_start: no valid grid table");
   HIP_TRY(h, hipMemcpyAsync(cs, h->cell_start, count * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return DSL_OK;
@@ -894,6 +948,32 @@ int dsl_device_pointers(dsl_handle* h, int buffer, const float** xyz, const int3
   xyz[2] = a.z;
   if (ids) *ids = h->ids[h->cur_ids];
   if (n) *n = ncur;
+  return DSL_OK;
+}
+
+int dsl_set_hash_vectors(dsl_handle* h, const float* vectors, int hash_bits) {
+  CHECK_HANDLE(h);
+  if (!h->lsh) return fail(h, DSL_ERR_INVALID, "dsl_set_hash_vectors: the handle is not in DSL_NEIGH_LSH_REF mode");
+  if (!vectors || hash_bits < 1 || hash_bits > 32) return fail(h, DSL_ERR_INVALID, "dsl_set_hash_vectors: 1..32 hash bits");
+  HIP_TRY(h, hipMemcpyAsync(h->hashv, vectors, (size_t)hash_bits * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->lsh_bits = hash_bits;
+  h->grid_valid = false;
+  return DSL_OK;
+}
+
+int dsl_lsh_download_table(dsl_handle* h, int32_t* out, size_t count) {
+  CHECK_HANDLE(h);
+  if (!h->lsh) return fail(h, DSL_ERR_INVALID, "dsl_lsh_download_table: the handle is not in DSL_NEIGH_LSH_REF mode");
+  const int B = h->prm.lsh_buckets, S = h->prm.lsh_bucket_size;
+  if (!out || count != (size_t)B * S) return fail(h, DSL_ERR_INVALID, "dsl_lsh_download_table: count must be buckets*bucket_size");
+  if (int rc = ensure_grid(h)) return rc;
+  std::vector<int> tab((size_t)B * h->lsh_cap), len(B);
+  HIP_TRY(h, hipMemcpyAsync(tab.data(), h->lsh_table, tab.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(len.data(), h->lsh_len, len.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int b = 0; b < B; ++b)  // GetData1D, lsh.go:70-80: zero-filled beyond the bucket's length
+    for (int j = 0; j < S; ++j) out[(size_t)b * S + j] = (j < len[b] && j < h->lsh_cap) ? tab[(size_t)b * h->lsh_cap + j] : 0;
   return DSL_OK;
 }
 
@@ -981,10 +1061,10 @@ static int field_div_curl(dsl_handle* h, int tensor_buffer, float* host_out, siz
     constexpr bool F = decltype(fast)::value;
     if (curl)
       hipLaunchKernelGGL((k_field_div_curl<F, kOpCurl>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
-                         h->cell_start, p, t, h->rho, out);
+                         neigh(h), p, t, h->rho, out);
     else
       hipLaunchKernelGGL((k_field_div_curl<F, kOpDiv>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
-                         h->cell_start, p, t, h->rho, out);
+                         neigh(h), p, t, h->rho, out);
   });
   HIP_TRY(h, hipGetLastError());
   const int* ids = h->ids[h->cur_ids];
@@ -1016,7 +1096,7 @@ int dsl_field_laplacian(dsl_handle* h, int scalar_buffer, float* host_out, size_
   CSoa3 p = cpos(h);
   by_math(h, [&](auto fast) {
     hipLaunchKernelGGL((k_field_laplacian<decltype(fast)::value>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
-                       h->cell_start, p, h->rho, field, h->scratch1);
+                       neigh(h), p, h->rho, field, h->scratch1);
   });
   hipLaunchKernelGGL(k_pack1, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, h->stage, h->ids[h->cur_ids], h->scratch1, 0);
   HIP_TRY(h, hipGetLastError());
@@ -1037,7 +1117,7 @@ int dsl_field_interpolate(dsl_handle* h, int scalar_buffer, const float* host_po
   HIP_TRY(h, hipMemcpyAsync(h->stage, host_positions, npos * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
   by_math(h, [&](auto fast) {
     hipLaunchKernelGGL((k_field_interpolate<decltype(fast)::value>), dim3(grid_for((int)npos)), dim3(kBlock), 0, h->stream,
-                       h->c, h->cell_start, p, h->rho, field, (int)npos, h->stage, h->scratch1);
+                       h->c, neigh(h), p, h->rho, field, (int)npos, h->stage, h->scratch1);
   });
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(host_out, h->scratch1, npos * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1119,7 +1199,7 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
                              h->tiles, h->n_tiles, h->cell_start, p, cpp, h->press, h->dstats);
         else
           by_math(h, [&](auto fast) {
-            hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, h->cell_start, p, cpp,
+            hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), p, cpp,
                                h->press, h->dstats);
           });
       });
@@ -1146,6 +1226,7 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
   CHECK_HANDLE(h);
   if (axis < -1 || axis > 2 || !(lo < hi)) return fail(h, DSL_ERR_INVALID, "dsl_slab_config: bad axis or empty range");
   if (h->pci_active) return fail(h, DSL_ERR_UNSUPPORTED, "slabs are implemented for the WCSPH step only");
+  if (h->lsh) return fail(h, DSL_ERR_UNSUPPORTED, "lsh_ref buckets are angular cones through the whole domain: no slabs");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
   h->c.slab_axis = axis;

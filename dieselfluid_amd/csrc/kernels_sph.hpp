@@ -22,13 +22,13 @@ struct CSoa3 {
 // field_types.go:39-42) so the force sweep does not call pow per neighbour.
 // ---------------------------------------------------------------------------------
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_density(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_density(DevConsts c, Neigh nb, CSoa3 p,
                                                     float* __restrict__ rho, float* __restrict__ pterm) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   float density = 0.0f;
-  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+  for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
     if (j == i) return;
     const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
     const float r2 = dist2<FAST>(dx, dy, dz);
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_density(DevConsts c, const int* __re
       }
     } else {
       const float dist = dsl_sqrt<false>(r2);
-      if (dist < c.h) {
+      if (in_support(c, nb, dist)) {
         const float w = kern_F<false>(c, dist);
         density += c.mass * w;
       }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_pterm(DevConsts c, const float* __re
 // accG accumulates grad*(Pi/rho_i^2 + Pj/rho_j^2); accV is LaplacianForce's running sum.
 // ---------------------------------------------------------------------------------
 template <bool FAST, bool WANT_G, bool WANT_V>
-__device__ __forceinline__ void force_sweep(const DevConsts& c, const int* __restrict__ cell_start, int i,
+__device__ __forceinline__ void force_sweep(const DevConsts& c, Neigh nb, int i,
                                             const CSoa3& p, const CSoa3& v, const float* __restrict__ rho,
                                             const float* __restrict__ pterm, float accG[3], float accV[3]) {
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
@@ -85,7 +85,7 @@ __device__ __forceinline__ void force_sweep(const DevConsts& c, const int* __res
     vzi = v.z[i];
   }
   if constexpr (WANT_G) pti = pterm[i];
-  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+  for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
     if (j == i) return;
     // dir = x_j - x_i (sph_field.go:189); |x_i - x_j| has the same squares
     const float dx = p.x[j] - xi, dy = p.y[j] - yi, dz = p.z[j] - zi;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void force_sweep(const DevConsts& c, const int* __res
       }
     } else {
       const float dist = dsl_sqrt<false>(r2);
-      if (!(dist < c.h)) return;
+      if (!in_support(c, nb, dist)) return;
       if constexpr (WANT_G) {
         float nx = 0.f, ny = 0.f, nz = 0.f;  // vector.go:322-331 Norm
         if (dist != 0.0f) {
@@ -157,7 +157,7 @@ __device__ __forceinline__ void force_sweep(const DevConsts& c, const int* __res
 
 // G: SPH.GradientPressureForce (fluid.go:164-172): F_i += sign * rho_i*m * accG
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, Neigh nb, CSoa3 p,
                                                      const float* __restrict__ rho, const float* __restrict__ pterm,
                                                      Soa3 f, const DevStats* stats, int honour_done) {
   if (honour_done && stats->pci_done) return;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, const int* __r
   if (i >= live_n(c)) return;
   float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
   CSoa3 nov{nullptr, nullptr, nullptr};
-  force_sweep<FAST, true, false>(c, cell_start, i, p, nov, rho, pterm, accG, accV);
+  force_sweep<FAST, true, false>(c, nb, i, p, nov, rho, pterm, accG, accV);
   const float dm = rho[i] * c.mass;
   const float gx = accG[0] * dm, gy = accG[1] * dm, gz = accG[2] * dm;
   const float sx = gx * c.pressure_sign, sy = gy * c.pressure_sign, sz = gz * c.pressure_sign;
@@ -176,12 +176,12 @@ __global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, const int* __r
 
 // V: SPH.ViscousAll (fluid.go:146-152): F_i += mu * LaplacianForce(i)
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, const int* __restrict__ cell_start, CSoa3 p, CSoa3 v,
+__global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, Neigh nb, CSoa3 p, CSoa3 v,
                                                     const float* __restrict__ rho, Soa3 f) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
   float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
-  force_sweep<FAST, false, true>(c, cell_start, i, p, v, rho, nullptr, accG, accV);
+  force_sweep<FAST, false, true>(c, nb, i, p, v, rho, nullptr, accG, accV);
   const float tx = accV[0] * c.mu, ty = accV[1] * c.mu, tz = accV[2] * c.mu;
   f.x[i] += tx;
   f.y[i] += ty;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, 
 // overwritten by Update (Press = 0, fluid.go:192) so it is not materialised.
 // ---------------------------------------------------------------------------------
 template <bool FAST, bool WANT_G, bool WANT_V>
-__global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const int* __restrict__ cell_start, CSoa3 pin,
+__global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh nb, CSoa3 pin,
                                                             CSoa3 vin, const float* __restrict__ rho,
                                                             const float* __restrict__ pterm, CSoa3 fin,
                                                             int forces_uniform, Soa3 pout, Soa3 vout,
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, const i
       fz = fin.z[i];
     }
     float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
-    if constexpr (WANT_G || WANT_V) force_sweep<FAST, WANT_G, WANT_V>(c, cell_start, i, pin, vin, rho, pterm, accG, accV);
+    if constexpr (WANT_G || WANT_V) force_sweep<FAST, WANT_G, WANT_V>(c, nb, i, pin, vin, rho, pterm, accG, accV);
     if constexpr (WANT_G) {
       const float dm = rho[i] * c.mass;
       const float gx = accG[0] * dm, gy = accG[1] * dm, gz = accG[2] * dm;
@@ -383,17 +383,17 @@ enum { kOpDiv = 0, kOpCurl = 1 };
 
 // Div (sph_field.go:203-227) / Curl (:272-294) of a tensor field t
 template <bool FAST, int OP>
-__global__ __launch_bounds__(kBlock) void k_field_div_curl(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_field_div_curl(DevConsts c, Neigh nb, CSoa3 p,
                                                            CSoa3 t, const float* __restrict__ rho, Soa3 out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   float div = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+  for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
     if (j == i) return;
     const float dx = p.x[j] - xi, dy = p.y[j] - yi, dz = p.z[j] - zi;
     const float dist = dsl_sqrt<FAST>(dist2<FAST>(dx, dy, dz));
-    if (!(dist < c.h)) return;
+    if (!in_support(c, nb, dist)) return;
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (dist != 0.0f) {
       nx = dsl_div<FAST>(dx, dist);
@@ -434,7 +434,7 @@ __device__ __forceinline__ float scalar_field(const DevConsts& c, int field, con
 
 // Laplacian (sph_field.go:230-248): sum_j m ((f_j - f_i)/rho_j) O2D(r)
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, Neigh nb, CSoa3 p,
                                                             const float* __restrict__ rho, int field,
                                                             float* __restrict__ out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -442,11 +442,11 @@ __global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, const i
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   const float fi = scalar_field<FAST>(c, field, rho, i);
   float sum = 0.f;
-  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+  for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
     if (j == i) return;
     const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
     const float dist = dsl_sqrt<FAST>(dist2<FAST>(dx, dy, dz));
-    if (!(dist < c.h)) return;
+    if (!in_support(c, nb, dist)) return;
     const float df = scalar_field<FAST>(c, field, rho, j) - fi;
     const float tt = c.mass * dsl_div<FAST>(df, rho[j]);
     const float u = tt * kern_O2D<FAST>(c, dist);
@@ -457,17 +457,17 @@ __global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, const i
 
 // Interpolate (sph_field.go:124-135) at arbitrary positions q: sum_j (m/rho_j) F(r) f_j
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_field_interpolate(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_field_interpolate(DevConsts c, Neigh nb, CSoa3 p,
                                                               const float* __restrict__ rho, int field, int nq,
                                                               const float* __restrict__ q, float* __restrict__ out) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= nq) return;
   const float xi = q[3 * k], yi = q[3 * k + 1], zi = q[3 * k + 2];
   float sum = 0.f;
-  for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+  for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
     const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
     const float dist = dsl_sqrt<FAST>(dist2<FAST>(dx, dy, dz));
-    if (!(dist < c.h)) return;
+    if (!in_support(c, nb, dist)) return;
     const float weight = dsl_div<FAST>(c.mass, rho[j]) * kern_F<FAST>(c, dist);
     const float u = weight * scalar_field<FAST>(c, field, rho, j);
     sum += u;
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, CSoa3 f, So
 // DF + pressure accumulate :76-92 -- SPHField.DensityF (sph_field.go:137-152): starts at
 // W0, includes self, neighbours' CURRENT positions around the PREDICTED position.
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, const int* __restrict__ cell_start, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, Neigh nb, CSoa3 p,
                                                         CSoa3 pp, float* __restrict__ press, DevStats* stats) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, const int* 
   if (i < live_n(c)) {
     const float xi = pp.x[i], yi = pp.y[i], zi = pp.z[i];
     float density = c.W0;
-    for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+    for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
       const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
       const float r2 = dist2<FAST>(dx, dy, dz);
       if constexpr (FAST) {
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, const int* 
         }
       } else {
         const float dist = dsl_sqrt<false>(r2);
-        if (dist < c.h) {
+        if (in_support(c, nb, dist)) {
           const float w = kern_F<false>(c, dist);
           density += c.mass * w;
         }

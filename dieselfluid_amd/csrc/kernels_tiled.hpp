@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
         acc = acc * (c.mass * c.A);
       } else {
         const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
-        for_each_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+        for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
           if (j == g) return;
           const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
           const float r2 = dist2<true>(dx, dy, dz);
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         } else {
           float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
           if constexpr (WANT_G || WANT_V)
-            force_sweep<true, WANT_G, WANT_V>(c, cell_start, g, pin, vin, rho, pterm, accG, accV);
+            force_sweep<true, WANT_G, WANT_V>(c, grid_neigh(cell_start), g, pin, vin, rho, pterm, accG, accV);
           gx = accG[0];
           gy = accG[1];
           gz = accG[2];
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
         density = __builtin_fmaf(acc + acc1, c.mass * c.A, c.W0);  // starts at W0, self included
       } else {
         density = c.W0;
-        for_each_candidate(c, cell_start, qx, qy, qz, [&](int j) {
+        for_each_grid_candidate(c, cell_start, qx, qy, qz, [&](int j) {
           const float dx = qx - p.x[j], dy = qy - p.y[j], dz = qz - p.z[j];
           const float r2 = dist2<true>(dx, dy, dz);
           if (r2 < c.hh) {

@@ -139,12 +139,57 @@ __device__ __forceinline__ bool slab_owned(const DevConsts& c, float x, float y,
   return p >= c.slab_lo && p < c.slab_hi;  // false for NaN
 }
 
-// Candidate sweep: the 27 cells around (x,y,z) as 9 x-runs; thanks to the x-fastest
-// linearisation the three cells of a run are one contiguous slot range.  Order: z, y,
-// then slots ascending -- the same order the oracle's DSLO_ORDER_CELL uses.
+// Where neighbour candidates come from: the uniform grid (cell_start) or the reference's
+// LSH sampler (sampler/lsh/lsh.go): one list of 100 samples per bucket, the bucket chosen by
+// the random-projection hash of the query position.
+constexpr int kLshSamples = 100;  // lsh.go:17
+struct Neigh {
+  const int* cell_start;
+  const int* samples;  // [buckets][kLshSamples]; non-null selects LSH mode
+  const float* hashv;  // [hash_bits][3]
+  int hash_bits, buckets;
+};
+__device__ __forceinline__ Neigh grid_neigh(const int* cell_start) { return Neigh{cell_start, nullptr, nullptr, 0, 0}; }
+
+// lsh.go:51-56 sgn, :102-111 Hash (dot product left to right, no fma: vector.go:268-276)
+__device__ __forceinline__ int lsh_hash(const Neigh& nb, float x, float y, float z) {
+  long long hash = 0;
+  for (int i = 0; i < nb.hash_bits; ++i) {
+    const float t0 = x * nb.hashv[3 * i], t1 = y * nb.hashv[3 * i + 1], t2 = z * nb.hashv[3 * i + 2];
+    const float d = (t0 + t1) + t2;
+    hash = (hash << 1) + (d <= 0.0f ? 0 : 1);
+  }
+  return (int)(hash % nb.buckets);
+}
+
+// In lsh_ref mode the reference relies on the kernel cut-offs alone (duplicates and
+// non-neighbours are visited); the geometric mode defines the neighbour set as dist < h.
+__device__ __forceinline__ bool in_support(const DevConsts& c, const Neigh& nb, float dist) {
+  return nb.samples != nullptr || dist < c.h;
+}
+
 template <class Body>
-__device__ __forceinline__ void for_each_candidate(const DevConsts& c, const int* __restrict__ cell_start,
-                                                   float x, float y, float z, Body&& body) {
+__device__ __forceinline__ void for_each_grid_candidate(const DevConsts& c, const int* __restrict__ cell_start,
+                                                        float x, float y, float z, Body&& body);
+
+// Candidate sweep.  LSH: the 100 samples of the query's bucket in list order (lsh.go:136-181).
+// Grid: the 27 cells around (x,y,z) as 9 x-runs; thanks to the x-fastest linearisation the
+// three cells of a run are one contiguous slot range.  Order: z, y, then slots ascending --
+// the same order the oracle's DSLO_ORDER_CELL uses.
+template <class Body>
+__device__ __forceinline__ void for_each_candidate(const DevConsts& c, const Neigh& nb, float x, float y, float z,
+                                                   Body&& body) {
+  if (nb.samples != nullptr) {
+    const int* l = nb.samples + (size_t)lsh_hash(nb, x, y, z) * kLshSamples;
+    for (int k = 0; k < kLshSamples; ++k) body(l[k]);
+  } else {
+    for_each_grid_candidate(c, nb.cell_start, x, y, z, body);
+  }
+}
+
+template <class Body>
+__device__ __forceinline__ void for_each_grid_candidate(const DevConsts& c, const int* __restrict__ cell_start,
+                                                        float x, float y, float z, Body&& body) {
   const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
   const int cx = cell_coord(x, c.gmin[0], c.inv_cell, nx);
   const int cy = cell_coord(y, c.gmin[1], c.inv_cell, ny);

@@ -161,6 +161,17 @@ class SPHEngine:
         self._ck(self._L.dsl_download_cell_start(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size))
         return out
 
+    # -- lsh_ref parity mode (sampler/lsh/lsh.go) ---------------------------------------
+    def set_hash_vectors(self, vectors):
+        v = np.ascontiguousarray(vectors, dtype=np.float32).reshape(-1, 3)
+        self._ck(self._L.dsl_set_hash_vectors(self._h, _fp(v), v.shape[0]))
+
+    def lsh_table(self) -> np.ndarray:
+        p = self.params
+        out = np.empty(p.lsh_buckets * p.lsh_bucket_size, dtype=np.int32)
+        self._ck(self._L.dsl_lsh_download_table(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size))
+        return out
+
     # -- model/sph.SPH passes -----------------------------------------------------
     def nn(self):
         self._ck(self._L.dsl_build_neighbours(self._h))

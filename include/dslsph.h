@@ -51,7 +51,9 @@ enum {
 };
 
 enum {
-  DSL_NEIGH_GRID = 1 /* all j with |xi-xj| < h via uniform-grid counting sort */
+  DSL_NEIGH_LSH_REF = 0, /* the reference's sampler: 8-bit random-projection LSH, 255 buckets, 100
+                            samples with duplicates (sampler/lsh/lsh.go); parity mode, EXACT math only */
+  DSL_NEIGH_GRID = 1     /* all j with |xi-xj| < h via uniform-grid counting sort */
 };
 enum {
   DSL_MATH_EXACT = 0, /* IEEE float32, one rounding per reference operation, f64 pow */
@@ -164,6 +166,13 @@ int dsl_download(dsl_handle *h, int buffer, float *host, size_t count);
  *   Valid until the next call that steps, uploads or rebuilds the neighbour table. */
 int dsl_download_decimated(dsl_handle *h, int buffer, int stride, float *host, size_t count);
 int dsl_device_pointers(dsl_handle *h, int buffer, const float **xyz, const int32_t **ids, int *n);
+
+/* lsh.Allocate's random projection vectors (sampler/lsh/lsh.go:32-40): hash_bits x 3 floats.
+ * The reference draws them from math/rand seeded with the wall-clock second; here they are an
+ * explicit input.  DSL_NEIGH_LSH_REF only. */
+int dsl_set_hash_vectors(dsl_handle *h, const float *vectors, int hash_bits);
+/* HashSampler.GetData1D (lsh.go:70-80): the flattened buckets x lsh_bucket_size table */
+int dsl_lsh_download_table(dsl_handle *h, int32_t *out, size_t count);
 
 /* SPH.NN() / HashSampler.UpdateSampler (fluid.go:100-102, sampler/lsh/lsh.go:126-133):
  * rebuilds the neighbour table (cell hash, histogram, prefix sum, counting-sort scatter). */
