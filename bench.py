@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--method", choices=["wcsph", "pcisph"], default="wcsph",
                     help="pcisph: BASELINE configs[2] style run (use --n3 160 for 4.1M particles); not the bench line")
     ap.add_argument("--pci-iters", type=int, default=4)
+    ap.add_argument("--extra-terms", action="store_true",
+                    help="BASELINE configs[4]: add the build-defined XSPH + cohesion (surface tension) terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -110,6 +112,9 @@ def main():
             p.pci_max_iters = args.pci_iters
             p.eos_w = p.eos_w / args.pci_iters
             p.delta = 1.0e-7
+        if args.extra_terms:
+            p.xsph_eps = 0.25
+            p.st_kappa = 10.0
         eng = SPHEngine(p, device=local_rank)
         eng.upload("positions", pos)
         eng.reset_forces()
@@ -191,7 +196,7 @@ def main():
                              f"density + pressure/viscosity force + integrate + walls, math={args.math}")
                 if args.method == "wcsph" else
                 (f"PCISPH dam-break ({args.pci_iters} correction iterations), {n_total} particles (n3={n3}), h=2dx, "
-                 f"uniform-grid neighbours, math={args.math}"),
+                 f"uniform-grid neighbours, math={args.math}") + (" + XSPH + cohesion terms" if args.extra_terms else ""),
                 "particles": n_total,
                 "parallelism": "single GPU" if world == 1 else f"{world} spatial slabs + 2h halo",
             },

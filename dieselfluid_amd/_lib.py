@@ -39,7 +39,8 @@ class Params(C.Structure):
         ("walls", C.c_int32), ("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("restitution", C.c_float),
         ("grid_min", C.c_float * 3), ("grid_max", C.c_float * 3),
         ("neigh_mode", C.c_int32), ("math_mode", C.c_int32), ("capacity", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("xsph_eps", C.c_float), ("st_kappa", C.c_float),
+        ("reserved", C.c_int32 * 5),
     ]
 
 

@@ -56,6 +56,7 @@ struct dsl_handle {
   float* pci[2][6] = {};
   float *rho = nullptr, *pterm = nullptr, *press = nullptr, *scratch1 = nullptr;
   float* gterm[3] = {};  // PCISPH: cached pressure-gradient force term
+  float* xsph[3] = {};   // build-defined XSPH correction of the current step (PCISPH path)
   unsigned int* nmask = nullptr;  // FAST: per-particle in-range masks from the density sweep (kMaskWords x cap)
   bool masks_valid = false;
   int *cellid = nullptr, *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
@@ -147,6 +148,8 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   c.wcsph_pressure_force = p.wcsph_pressure_force;
   c.wcsph_viscosity = p.wcsph_viscosity;
   c.pci_max_error = p.pci_max_error;
+  c.xsph_eps = p.xsph_eps;
+  c.st_kappa = p.st_kappa;
   c.walls = p.walls;
   c.rest = p.restitution;
   c.inv_cell = 1.0f / hh;
@@ -422,11 +425,22 @@ int force_integrate(dsl_handle* h) {
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tiles, h->n_tiles,    \
                      h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats,                         \
                      h->masks_valid ? h->nmask : nullptr, h->cap)
-      if (G && V) DSL_LAUNCH_FT(true, true);
+#define DSL_LAUNCH_FTX(GG, VV)                                                                                  \
+  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, true>), g, b, 0, h->stream, c, h->tg,     \
+                     h->tiles, h->n_tiles, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats,   \
+                     h->masks_valid ? h->nmask : nullptr, h->cap)
+      const bool XS = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
+      if (XS) {
+        if (G && V) DSL_LAUNCH_FTX(true, true);
+        else if (G) DSL_LAUNCH_FTX(true, false);
+        else if (V) DSL_LAUNCH_FTX(false, true);
+        else DSL_LAUNCH_FTX(false, false);
+      } else if (G && V) DSL_LAUNCH_FT(true, true);
       else if (G) DSL_LAUNCH_FT(true, false);
       else if (V) DSL_LAUNCH_FT(false, true);
       else DSL_LAUNCH_FT(false, false);
 #undef DSL_LAUNCH_FT
+#undef DSL_LAUNCH_FTX
     });
   } else
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
@@ -464,25 +478,31 @@ int gradient_pass(dsl_handle* h, int honour_done) {
   });
 }
 
-int viscous_pass(dsl_handle* h) {
+// with_xs: also add the cohesion force and store the XSPH correction (PCISPH with the
+// build-defined terms)
+int viscous_pass(dsl_handle* h, int with_xs = 0) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h), v = cvel(h);
   Soa3 f = mfrc(h);
+  Soa3 xs{h->xsph[0], h->xsph[1], h->xsph[2]};
   return timed(h, DSL_K_VISCOUS, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_viscous<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         neigh(h), p, v, h->rho, f);
+                         neigh(h), p, v, h->rho, f, with_xs, xs);
     });
   });
 }
 
-int update_pass(dsl_handle* h) {
+// use_xs: Update advects positions with v + the XSPH correction stored by the viscous sweep
+int update_pass(dsl_handle* h, bool use_xs = false) {
   const DevConsts& c = h->c;
+  CSoa3 xs{use_xs ? h->xsph[0] : nullptr, use_xs ? h->xsph[1] : nullptr, use_xs ? h->xsph[2] : nullptr};
   Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
   CSoa3 f = cfrc(h);
   const int uni = h->forces_uniform ? 1 : 0;
   int rc = timed(h, DSL_K_UPDATE, [&] {
-    hipLaunchKernelGGL(k_update, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c, p, v, f, uni, h->dstats);
+    hipLaunchKernelGGL(k_update, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c, p, v, f, uni, h->dstats,
+                       xs);
   });
   if (rc) return rc;
   h->forces_uniform = true;
@@ -533,7 +553,10 @@ void free_all(dsl_handle* h) {
     }
     for (int k = 0; k < 3; ++k) (void)hipFree(h->frc[w][k]);
     if (w == 0)
-      for (int k = 0; k < 3; ++k) (void)hipFree(h->gterm[k]);
+      for (int k = 0; k < 3; ++k) {
+        (void)hipFree(h->gterm[k]);
+        (void)hipFree(h->xsph[k]);
+      }
     (void)hipFree(h->ids[w]);
   }
   (void)hipFree(h->rho);
@@ -570,6 +593,8 @@ int alloc_pci(dsl_handle* h) {
   if (h->pci[0][0]) return DSL_OK;
   for (int k = 0; k < 3; ++k)
     if (int rc = dev_alloc(h, &h->gterm[k], (size_t)h->cap)) return rc;
+  for (int k = 0; k < 3; ++k)
+    if (int rc = dev_alloc(h, &h->xsph[k], (size_t)h->cap)) return rc;
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 6; ++k)
       if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
@@ -1167,13 +1192,20 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
     CSoa3 p = cpos(h), v = cvel(h);
     Soa3 F = mfrc(h);
     CSoa3 cF{F.x, F.y, F.z};
+    const bool XS = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
     if (tiled) {
       Soa3 G{h->gterm[0], h->gterm[1], h->gterm[2]};
       Soa3 none{nullptr, nullptr, nullptr};
-      int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45
-        hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
-                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+      Soa3 xs{h->xsph[0], h->xsph[1], h->xsph[2]};
+      int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45 (+ cohesion, XSPH sums)
+        if (XS)
+          hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
+                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                             h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+        else
+          hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
+                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                             h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
       });
       if (rc) return rc;
       rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
@@ -1183,7 +1215,7 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
       });
       if (rc) return rc;
     } else {
-      if (int rc = viscous_pass(h)) return rc;
+      if (int rc = viscous_pass(h, XS ? 1 : 0)) return rc;
     }
     hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats);
     for (int it = 0; it < h->prm.pci_max_iters; ++it) {
@@ -1216,7 +1248,7 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
       hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, c, h->dstats);
     }
     HIP_TRY(h, hipGetLastError());
-    if (int rc = update_pass(h)) return rc;         // Update :101
+    if (int rc = update_pass(h, XS)) return rc;     // Update :101 (positions advect with v + XSPH)
     h->steps++;
   }
   return DSL_OK;

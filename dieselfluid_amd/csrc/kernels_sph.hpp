@@ -73,13 +73,17 @@ __global__ __launch_bounds__(kBlock) void k_pterm(DevConsts c, const float* __re
 // Shared neighbour sweep for G (sph_field.go:175-200) and V (sph_field.go:251-269).
 // accG accumulates grad*(Pi/rho_i^2 + Pj/rho_j^2); accV is LaplacianForce's running sum.
 // ---------------------------------------------------------------------------------
+// accX / accS (optional, both or none): the build-defined XSPH sum_j (m/rho_j)(v_j - v_i) F(r)
+// and cohesion sum_j m (x_j - x_i) F(r) terms; they need v even when WANT_V is false.
 template <bool FAST, bool WANT_G, bool WANT_V>
 __device__ __forceinline__ void force_sweep(const DevConsts& c, Neigh nb, int i,
                                             const CSoa3& p, const CSoa3& v, const float* __restrict__ rho,
-                                            const float* __restrict__ pterm, float accG[3], float accV[3]) {
+                                            const float* __restrict__ pterm, float accG[3], float accV[3],
+                                            float* accX = nullptr, float* accS = nullptr) {
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   float vxi = 0.f, vyi = 0.f, vzi = 0.f, pti = 0.f;
-  if constexpr (WANT_V) {
+  const bool xs = accX != nullptr;
+  if (WANT_V || xs) {
     vxi = v.x[i];
     vyi = v.y[i];
     vzi = v.z[i];
@@ -92,6 +96,17 @@ __device__ __forceinline__ void force_sweep(const DevConsts& c, Neigh nb, int i,
     const float r2 = dist2<FAST>(dx, dy, dz);
     if constexpr (FAST) {
       if (!(r2 < c.hh)) return;
+      if (xs) {
+        const float q2 = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+        const float fw = c.A * q2 * q2;
+        const float ws = c.mass * fw, wx = ws * __builtin_amdgcn_rcpf(rho[j]);
+        accS[0] = __builtin_fmaf(dx, ws, accS[0]);
+        accS[1] = __builtin_fmaf(dy, ws, accS[1]);
+        accS[2] = __builtin_fmaf(dz, ws, accS[2]);
+        accX[0] = __builtin_fmaf(v.x[j] - vxi, wx, accX[0]);
+        accX[1] = __builtin_fmaf(v.y[j] - vyi, wx, accX[1]);
+        accX[2] = __builtin_fmaf(v.z[j] - vzi, wx, accX[2]);
+      }
       const float rinv = __builtin_amdgcn_rsqf(r2);  // r2 == 0 -> inf, handled below
       const float dist = r2 * rinv;
       const float q = __builtin_fmaf(-(r2 > 0.f ? dist : 0.f), c.inv_h, 1.0f);
@@ -119,6 +134,19 @@ __device__ __forceinline__ void force_sweep(const DevConsts& c, Neigh nb, int i,
     } else {
       const float dist = dsl_sqrt<false>(r2);
       if (!in_support(c, nb, dist)) return;
+      if (xs) {
+        const float fw = kern_F<false>(c, dist);
+        const float ws = c.mass * fw;
+        const float tsx = dx * ws, tsy = dy * ws, tsz = dz * ws;
+        accS[0] = accS[0] + tsx;
+        accS[1] = accS[1] + tsy;
+        accS[2] = accS[2] + tsz;
+        const float wx = (c.mass / rho[j]) * fw;
+        const float txx = (v.x[j] - vxi) * wx, txy = (v.y[j] - vyi) * wx, txz = (v.z[j] - vzi) * wx;
+        accX[0] = accX[0] + txx;
+        accX[1] = accX[1] + txy;
+        accX[2] = accX[2] + txz;
+      }
       if constexpr (WANT_G) {
         float nx = 0.f, ny = 0.f, nz = 0.f;  // vector.go:322-331 Norm
         if (dist != 0.0f) {
@@ -175,17 +203,29 @@ __global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, Neigh nb, CSoa
 }
 
 // V: SPH.ViscousAll (fluid.go:146-152): F_i += mu * LaplacianForce(i)
+// with_xs (PCISPH with the build-defined terms): the same sweep also adds the cohesion force and
+// stores the XSPH correction for Update
 template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, Neigh nb, CSoa3 p, CSoa3 v,
-                                                    const float* __restrict__ rho, Soa3 f) {
+                                                    const float* __restrict__ rho, Soa3 f, int with_xs, Soa3 xsph) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
-  float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
-  force_sweep<FAST, false, true>(c, nb, i, p, v, rho, nullptr, accG, accV);
+  float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f}, accX[3] = {0.f, 0.f, 0.f}, accS[3] = {0.f, 0.f, 0.f};
+  force_sweep<FAST, false, true>(c, nb, i, p, v, rho, nullptr, accG, accV, with_xs ? accX : nullptr,
+                                 with_xs ? accS : nullptr);
   const float tx = accV[0] * c.mu, ty = accV[1] * c.mu, tz = accV[2] * c.mu;
   f.x[i] += tx;
   f.y[i] += ty;
   f.z[i] += tz;
+  if (with_xs) {
+    const float sx = accS[0] * c.st_kappa, sy = accS[1] * c.st_kappa, sz = accS[2] * c.st_kappa;
+    f.x[i] += sx;
+    f.y[i] += sy;
+    f.z[i] += sz;
+    xsph.x[i] = accX[0] * c.xsph_eps;
+    xsph.y[i] = accX[1] * c.xsph_eps;
+    xsph.z[i] = accX[2] * c.xsph_eps;
+  }
 }
 
 // X: SPH.ExternalAll (fluid.go:155-161)
@@ -200,13 +240,20 @@ __global__ __launch_bounds__(kBlock) void k_external(int n, Soa3 f, float ex, fl
 // U: SPH.Update (fluid.go:175-197) for one particle, then the build-defined wall box.
 __device__ __forceinline__ void integrate_core(const DevConsts& c, float fx, float fy, float fz, float& px, float& py,
                                                float& pz, float& vx, float& vy, float& vz, unsigned int& vbits,
-                                               unsigned int& fbits) {
+                                               unsigned int& fbits, float xsx = 0.f, float xsy = 0.f,
+                                               float xsz = 0.f) {
   const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
   const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
   vx += dvx;
   vy += dvy;
   vz += dvz;
-  const float dpx = vx * c.dt, dpy = vy * c.dt, dpz = vz * c.dt;
+  float ux = vx, uy = vy, uz = vz;
+  if (c.xsph_eps != 0.0f) {  // build-defined XSPH: positions advect with the smoothed velocity
+    ux = vx + xsx;
+    uy = vy + xsy;
+    uz = vz + xsz;
+  }
+  const float dpx = ux * c.dt, dpy = uy * c.dt, dpz = uz * c.dt;
   px += dpx;
   py += dpy;
   pz += dpz;
@@ -233,40 +280,17 @@ __device__ __forceinline__ void integrate_core(const DevConsts& c, float fx, flo
 }
 
 __device__ __forceinline__ void integrate_one(const DevConsts& c, float fx, float fy, float fz, float& px, float& py,
-                                              float& pz, float& vx, float& vy, float& vz, DevStats* stats) {
-  const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
-  const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
-  vx += dvx;
-  vy += dvy;
-  vz += dvz;
-  const float dpx = vx * c.dt, dpy = vy * c.dt, dpz = vz * c.dt;
-  px += dpx;
-  py += dpy;
-  pz += dpz;
-  const float vm = dsl_sqrt<false>(dist2<false>(vx, vy, vz));
-  const float fm = dsl_sqrt<false>(dist2<false>(fx, fy, fz));
-  wave_atomic_max(&stats->max_vel_bits, nonneg_bits(vm));
-  wave_atomic_max(&stats->max_f_bits, nonneg_bits(fm));
-  if (c.walls) {
-    float* P[3] = {&px, &py, &pz};
-    float* V[3] = {&vx, &vy, &vz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (*P[a] < c.bmin[a]) {
-        *P[a] = c.bmin[a];
-        if (*V[a] < 0.0f) *V[a] = -*V[a] * c.rest;
-      }
-      if (*P[a] > c.bmax[a]) {
-        *P[a] = c.bmax[a];
-        if (*V[a] > 0.0f) *V[a] = -*V[a] * c.rest;
-      }
-    }
-  }
+                                              float& pz, float& vx, float& vy, float& vz, DevStats* stats,
+                                              float xsx = 0.f, float xsy = 0.f, float xsz = 0.f) {
+  unsigned int vb = 0u, fb = 0u;
+  integrate_core(c, fx, fy, fz, px, py, pz, vx, vy, vz, vb, fb, xsx, xsy, xsz);
+  wave_atomic_max(&stats->max_vel_bits, vb);
+  wave_atomic_max(&stats->max_f_bits, fb);
 }
 
 // stand-alone Update: in place (per-particle, no neighbour reads)
 __global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, CSoa3 f, int forces_uniform,
-                                                   DevStats* stats) {
+                                                   DevStats* stats, CSoa3 xsph) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   float fx = c.reset[0], fy = c.reset[1], fz = c.reset[2];
   float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
@@ -288,7 +312,13 @@ __global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, 
   }
   const bool owned = live && slab_owned(c, px, py, pz);
   if (!owned) fx = fy = fz = vx = vy = vz = 0.f;  // keep ghosts out of the max|v|, max|F| counters
-  integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats);
+  float xsx = 0.f, xsy = 0.f, xsz = 0.f;
+  if (owned && c.xsph_eps != 0.0f && xsph.x != nullptr) {
+    xsx = xsph.x[i];
+    xsy = xsph.y[i];
+    xsz = xsph.z[i];
+  }
+  integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats, xsx, xsy, xsz);
   if (owned) {
     p.x[i] = px;
     p.y[i] = py;
@@ -320,6 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh n
   const bool live = i < live_n(c);
   const bool owned = live && slab_owned(c, pin.x[i], pin.y[i], pin.z[i]);
   float fx = 0.f, fy = 0.f, fz = 0.f, px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+  float accX[3] = {0.f, 0.f, 0.f}, accS[3] = {0.f, 0.f, 0.f};
   if (owned) {
     fx = c.reset[0];
     fy = c.reset[1];
@@ -330,7 +361,10 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh n
       fz = fin.z[i];
     }
     float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
-    if constexpr (WANT_G || WANT_V) force_sweep<FAST, WANT_G, WANT_V>(c, nb, i, pin, vin, rho, pterm, accG, accV);
+    const bool xs = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
+    if (WANT_G || WANT_V || xs)
+      force_sweep<FAST, WANT_G, WANT_V>(c, nb, i, pin, vin, rho, pterm, accG, accV, xs ? accX : nullptr,
+                                        xs ? accS : nullptr);
     if constexpr (WANT_G) {
       const float dm = rho[i] * c.mass;
       const float gx = accG[0] * dm, gy = accG[1] * dm, gz = accG[2] * dm;
@@ -345,6 +379,12 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh n
       fy += ty;
       fz += tz;
     }
+    if (xs) {
+      const float sx = accS[0] * c.st_kappa, sy = accS[1] * c.st_kappa, sz = accS[2] * c.st_kappa;
+      fx += sx;
+      fy += sy;
+      fz += sz;
+    }
     fx += c.ext[0];
     fy += c.ext[1];
     fz += c.ext[2];
@@ -355,7 +395,8 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh n
     vy = vin.y[i];
     vz = vin.z[i];
   }
-  integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats);
+  integrate_one(c, fx, fy, fz, px, py, pz, vx, vy, vz, stats, accX[0] * c.xsph_eps, accX[1] * c.xsph_eps,
+                accX[2] * c.xsph_eps);
   if (owned) {
     pout.x[i] = px;
     pout.y[i] = py;

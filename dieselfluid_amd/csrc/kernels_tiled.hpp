@@ -349,7 +349,9 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
 //   kOutStore      pout = G-term (PCISPH: the gradient term is the same in every iteration)
 constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
 
-template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate>
+// WANT_XS adds the build-defined XSPH and cohesion sums (BASELINE configs[4]) to the same sweep;
+// with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
+template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false>
 __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
             o[1] = pin.y[g];
             o[2] = pin.z[g];
             o[3] = WANT_G ? pterm[g] : 0.f;
-            if constexpr (WANT_V) {
+            if constexpr (WANT_V || WANT_XS) {
               o[4] = vin.x[g];
               o[5] = vin.y[g];
               o[6] = vin.z[g];
@@ -389,10 +391,10 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
             float4 a = make_float4(kFar, kFar, kFar, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (real) {
               a = make_float4(o[0], o[1], o[2], o[3]);
-              if constexpr (WANT_V) b = make_float4(o[4], o[5], o[6], __builtin_amdgcn_rcpf(o[7]));
+              if constexpr (WANT_V || WANT_XS) b = make_float4(o[4], o[5], o[6], __builtin_amdgcn_rcpf(o[7]));
             }
             A[slot] = a;
-            if constexpr (WANT_V) B[slot] = b;
+            if constexpr (WANT_V || WANT_XS) B[slot] = b;
           });
     }
     __syncthreads();
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         g = m.row_gs[srow] + off;
       }
       float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
+      float xsx = 0.f, xsy = 0.f, xsz = 0.f;  // XSPH sum / correction
       bool owned = false;
       if (live) {
         px = pin.x[g];
@@ -422,11 +425,13 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
       }
       if (owned) {
         float gx = 0.f, gy = 0.f, gz = 0.f, lx_ = 0.f, ly_ = 0.f, lz_ = 0.f;
+        float cohx = 0.f, cohy = 0.f, cohz = 0.f;  // cohesion sum
         if (!ovf) {
-          if constexpr (WANT_G || WANT_V) {
+          if constexpr (WANT_G || WANT_V || WANT_XS) {
             const float pti = WANT_G ? pterm[g] : 0.f;
             const float ninvh = -c.inv_h;
-            float lw_ = 0.f;
+            float lw_ = 0.f, xw_ = 0.f;
+            const float ninvhh = -c.inv_hh;
             const int lx = cell_coord(px, c.gmin[0], c.inv_cell, c.dims[0]) - x0;
             // full per-pair arithmetic for candidate record j
             auto pair = [&](int j) {
@@ -443,14 +448,29 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                 gy = __builtin_fmaf(dyy, k, gy);
                 gz = __builtin_fmaf(dzz, k, gz);
               }
+              float4 b = a;
+              if constexpr (WANT_V || WANT_XS) b = B[j];
               if constexpr (WANT_V) {
                 // sum_j (v_j - v_i) w_j = sum_j v_j w_j - v_i sum_j w_j
-                const float4 b = B[j];
                 const float w = q * b.w;
                 lx_ = __builtin_fmaf(b.x, w, lx_);
                 ly_ = __builtin_fmaf(b.y, w, ly_);
                 lz_ = __builtin_fmaf(b.z, w, lz_);
                 lw_ += w;
+              }
+              if constexpr (WANT_XS) {
+                // F(r)/A = (1 - r^2/h^2)^2 for both build-defined terms; the particle itself has d = 0
+                // and v_j = v_i, so it contributes nothing
+                const float q2 = fma_clamp01(r2, ninvhh, 1.0f);
+                const float fw = q2 * q2;
+                cohx = __builtin_fmaf(dx, fw, cohx);
+                cohy = __builtin_fmaf(dyy, fw, cohy);
+                cohz = __builtin_fmaf(dzz, fw, cohz);
+                const float wx = fw * b.w;
+                xsx = __builtin_fmaf(b.x, wx, xsx);
+                xsy = __builtin_fmaf(b.y, wx, xsy);
+                xsz = __builtin_fmaf(b.z, wx, xsz);
+                xw_ += wx;
               }
             };
             const bool masked = nmask != nullptr && nmask[(size_t)9 * mstride + g] != 0u;
@@ -493,6 +513,15 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
               ly_ = __builtin_fmaf(-vy, lw_, ly_);
               lz_ = __builtin_fmaf(-vz, lw_, lz_);
             }
+            if constexpr (WANT_XS) {
+              const float ma = c.mass * c.A;
+              cohx *= ma;
+              cohy *= ma;
+              cohz *= ma;
+              xsx = __builtin_fmaf(-vx, xw_, xsx) * ma;
+              xsy = __builtin_fmaf(-vy, xw_, xsy) * ma;
+              xsz = __builtin_fmaf(-vz, xw_, xsz) * ma;
+            }
             // constant factors taken out of the sums: -O1D = -B q^2, O2D = C q, times m
             const float sg = -c.B;
             gx *= sg;
@@ -504,9 +533,17 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
             lz_ *= sv;
           }
         } else {
-          float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
-          if constexpr (WANT_G || WANT_V)
-            force_sweep<true, WANT_G, WANT_V>(c, grid_neigh(cell_start), g, pin, vin, rho, pterm, accG, accV);
+          float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f}, accX[3] = {0.f, 0.f, 0.f},
+                accS[3] = {0.f, 0.f, 0.f};
+          if constexpr (WANT_G || WANT_V || WANT_XS)
+            force_sweep<true, WANT_G, WANT_V>(c, grid_neigh(cell_start), g, pin, vin, rho, pterm, accG, accV,
+                                              WANT_XS ? accX : nullptr, WANT_XS ? accS : nullptr);
+          cohx = accS[0];
+          cohy = accS[1];
+          cohz = accS[2];
+          xsx = accX[0];
+          xsy = accX[1];
+          xsz = accX[2];
           gx = accG[0];
           gy = accG[1];
           gz = accG[2];
@@ -535,6 +572,14 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
           fy = __builtin_fmaf(ly_, c.mu, fy);
           fz = __builtin_fmaf(lz_, c.mu, fz);
         }
+        if constexpr (WANT_XS) {
+          fx = __builtin_fmaf(cohx, c.st_kappa, fx);
+          fy = __builtin_fmaf(cohy, c.st_kappa, fy);
+          fz = __builtin_fmaf(cohz, c.st_kappa, fz);
+          xsx *= c.xsph_eps;
+          xsy *= c.xsph_eps;
+          xsz *= c.xsph_eps;
+        }
         if constexpr (OUT == kOutIntegrate) {
           fx += c.ext[0];
           fy += c.ext[1];
@@ -547,6 +592,11 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         pout.x[g] += fx;
         pout.y[g] += fy;
         pout.z[g] += fz;
+        if constexpr (WANT_XS) {  // XSPH correction for the later Update
+          vout.x[g] = xsx;
+          vout.y[g] = xsy;
+          vout.z[g] = xsz;
+        }
         continue;
       }
       if constexpr (OUT == kOutStore) {
@@ -556,7 +606,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         continue;
       }
       float npx = px, npy = py, npz = pz, nvx = vx, nvy = vy, nvz = vz;
-      integrate_core(c, fx, fy, fz, npx, npy, npz, nvx, nvy, nvz, vbits, fbits);
+      integrate_core(c, fx, fy, fz, npx, npy, npz, nvx, nvy, nvz, vbits, fbits, xsx, xsy, xsz);
       if (owned) {
         pout.x[g] = npx;
         pout.y[g] = npy;

@@ -28,6 +28,7 @@ struct DevConsts {
   float reset[3], ext[3];
   int wcsph_pressure_force, wcsph_viscosity;
   float pci_max_error;
+  float xsph_eps, st_kappa;  // build-defined XSPH / cohesion terms, 0 = off
   int walls;
   float bmin[3], bmax[3], rest;
   // uniform grid: cell edge = h, x-fastest linearisation

@@ -101,7 +101,11 @@ typedef struct dsl_params {
   int32_t math_mode;  /* DSL_MATH_*     */
   int32_t capacity;   /* particle slots to allocate (>= n_particles); 0 = n_particles.
                          Slab ranks need room for migrants and ghosts. */
-  int32_t reserved[7];
+  /* build-defined terms of BASELINE configs[4] (no reference counterpart), 0 = off:
+   *   xsph_eps: positions advect with v + eps * sum_j (m/rho_j) (v_j - v_i) F(r_ij)
+   *   st_kappa: cohesion force F_i += kappa * sum_j m (x_j - x_i) F(r_ij)          */
+  float xsph_eps, st_kappa;
+  int32_t reserved[5];
 } dsl_params;
 
 /* Counters the reference keeps on the host (fluid.go:25-26,186-191) plus the PCISPH loop

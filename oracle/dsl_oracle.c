@@ -527,6 +527,7 @@ void dslo_sph_free(dslo_sph *s) {
   dslo_particles_free(&s->parts);
   free(s->pci_pos);
   free(s->pci_vel);
+  free(s->xsph);
   free(s->scratch);
   free(s);
 }
@@ -820,7 +821,9 @@ void dslo_update(dslo_sph *s) { /* fluid.go:175-197 */
       q.velocity[a] += dv;
     }
     for (int a = 0; a < 3; a++) {
-      float dx = q.velocity[a] * ts;
+      float va = q.velocity[a];
+      if (s->prm.xsph_eps != 0.0f && s->xsph) va = va + s->xsph[3 * i + a]; /* build-defined XSPH */
+      float dx = va * ts;
       q.position[a] += dx;
     }
     float vm = dslo_vec_mag(q.velocity, 3);
@@ -842,6 +845,64 @@ void dslo_update(dslo_sph *s) { /* fluid.go:175-197 */
       }
     }
     dslo_particles_set(&s->parts, i, &q);
+  }
+}
+
+/* build-defined (BASELINE configs[4]): cohesion F_i += kappa * sum_{j != i} m (x_j - x_i) F(r) */
+void dslo_surface_tension_all(dslo_sph *s) {
+  if (s->prm.st_kappa == 0.0f) return;
+  for (int i = 0; i < s->particles; i++) {
+    dslo_particle pi = dslo_particles_get(&s->parts, i);
+    const int *samples;
+    int len = dslo_get_samples(s, i, &samples);
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < len; j++) {
+      int jIndex = samples[j];
+      if (jIndex == i) continue;
+      dslo_particle q = dslo_particles_get(&s->parts, jIndex);
+      float d[3];
+      vsub3(q.position, pi.position, d);
+      float dist = dslo_vec_mag(d, 3);
+      if (!in_support(s, dist)) continue;
+      float w = s->parts.mass * dslo_kernel_F(&s->kern, dist);
+      for (int a = 0; a < 3; a++) {
+        float t = d[a] * w;
+        acc[a] = acc[a] + t;
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      float t = acc[a] * s->prm.st_kappa;
+      pi.force[a] += t;
+    }
+    dslo_particles_set(&s->parts, i, &pi);
+  }
+}
+
+/* build-defined (BASELINE configs[4]): XSPH correction eps * sum_{j != i} (m/rho_j) (v_j - v_i) F(r),
+ * evaluated before Update (old velocities); Update advects positions with v + correction. */
+void dslo_xsph_all(dslo_sph *s) {
+  if (s->prm.xsph_eps == 0.0f) return;
+  if (!s->xsph) s->xsph = (float *)calloc((size_t)s->particles * 3 + 1, sizeof(float));
+  for (int i = 0; i < s->particles; i++) {
+    dslo_particle pi = dslo_particles_get(&s->parts, i);
+    const int *samples;
+    int len = dslo_get_samples(s, i, &samples);
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < len; j++) {
+      int jIndex = samples[j];
+      if (jIndex == i) continue;
+      dslo_particle q = dslo_particles_get(&s->parts, jIndex);
+      float dist = dslo_vec_dist3(pi.position, q.position);
+      if (!in_support(s, dist)) continue;
+      float w = (s->parts.mass / q.density) * dslo_kernel_F(&s->kern, dist);
+      float dv[3];
+      vsub3(q.velocity, pi.velocity, dv);
+      for (int a = 0; a < 3; a++) {
+        float t = dv[a] * w;
+        acc[a] = acc[a] + t;
+      }
+    }
+    for (int a = 0; a < 3; a++) s->xsph[3 * i + a] = acc[a] * s->prm.xsph_eps;
   }
 }
 
@@ -920,8 +981,10 @@ void dslo_wcsph_step(dslo_sph *s) {
   dslo_density_all(s);
   if (s->prm.wcsph_pressure_force) dslo_gradient_pressure_force(s);
   if (s->prm.wcsph_viscosity) dslo_viscous_all(s);
+  dslo_surface_tension_all(s);
   dslo_external_all(s, s->prm.external);
   dslo_pressure_all(s);
+  dslo_xsph_all(s);
   dslo_update(s);
   dslo_cfl(s);
 }
@@ -945,6 +1008,7 @@ void dslo_pcisph_step(dslo_sph *s) {
   dslo_sampler_update(s);
   dslo_density_all(s);
   dslo_viscous_all(s);
+  dslo_surface_tension_all(s);
   float max_error_ratio = 0.0f, density_error = 0.0f;
   int iters = 0;
   for (int iter = 0; iter < s->prm.pci_max_iters; iter++) {
@@ -977,6 +1041,7 @@ void dslo_pcisph_step(dslo_sph *s) {
   }
   s->pci_last_error = max_error_ratio;
   s->pci_last_iters = iters;
+  dslo_xsph_all(s);
   dslo_update(s); /* :101 */
 }
 

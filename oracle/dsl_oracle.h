@@ -113,6 +113,10 @@ typedef struct {
   /* > 0: ParticleArray.SetReferenceDensity(d0) after construction (particle_array.go:35-37);
    * 0: keep NewParticleArray's ReferenceDensity = ref_density * mass (particle_array.go:26) */
   float d0_override;
+  /* build-defined terms of BASELINE configs[4] (no reference counterpart), 0 = off:
+   *   xsph_eps : positions advect with v + eps * sum_j (m/rho_j) (v_j - v_i) F(r_ij)
+   *   st_kappa : cohesion force F_i += kappa * sum_j m (x_j - x_i) F(r_ij)            */
+  float xsph_eps, st_kappa;
 } dslo_params;
 
 /* model/sph/fluid.go:23-33 (+ solver state of pcisph_darwin.go:28-41) */
@@ -123,6 +127,7 @@ typedef struct {
   dslo_sampler smp;
   float time, max_vel, max_f, cache_life, mu, delta;
   int particles;
+  float *xsph; /* n*3: XSPH velocity correction of the current step (build-defined) */
   /* PCISPH predictor state; allocated by dslo_pcisph_begin */
   float *pci_pos, *pci_vel;
   float pci_last_error;
@@ -189,6 +194,8 @@ void dslo_update(dslo_sph *s);
 float dslo_cache_incr(dslo_sph *s, int *rebuilt);
 float dslo_pcidelta(dslo_sph *s);
 float dslo_density_f(dslo_sph *s, const float pos[3]);
+void dslo_surface_tension_all(dslo_sph *s); /* build-defined */
+void dslo_xsph_all(dslo_sph *s);            /* build-defined */
 
 /* ---- unused-by-solvers field operators: model/field/sph_field.go:124-135,203-294 ---- */
 float dslo_field_div(dslo_sph *s, int i, int tensor_field);

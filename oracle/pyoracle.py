@@ -77,6 +77,8 @@ class Params(C.Structure):
         ("grid_min", C.c_float * 3),
         ("grid_max", C.c_float * 3),
         ("d0_override", C.c_float),
+        ("xsph_eps", C.c_float),
+        ("st_kappa", C.c_float),
     ]
 
 

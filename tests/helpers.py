@@ -15,7 +15,7 @@ def oracle_params(p, mode=po.NEIGH_GRID, order=po.ORDER_CELL, n3=0):
     q.d0_override = p.ref_density
     for name in ("h", "mass", "ref_density", "mu", "dt", "eos_w", "eos_gamma", "eos_d0_grad", "pressure_sign",
                  "visc_running_mass", "wcsph_pressure_force", "wcsph_viscosity", "pci_max_iters", "pci_max_error",
-                 "walls", "restitution"):
+                 "walls", "restitution", "xsph_eps", "st_kappa"):
         setattr(q, name, getattr(p, name))
     for name in ("force_reset", "external", "box_min", "box_max", "grid_min", "grid_max"):
         for a in range(3):

@@ -232,6 +232,41 @@ def test_field_operators(math_mode, tol):
     assert helpers.rel_err(eng.field_div("forces"), ora.field_div("force")) < 2 * tol
 
 
+@pytest.mark.parametrize("math_mode,tol_x,tol_v", [(EXACT, 1e-6, 1e-4), (FAST, 1e-5, 1e-3)])
+@pytest.mark.parametrize("method", ["wcsph", "pcisph"])
+def test_xsph_and_surface_tension_terms(method, math_mode, tol_x, tol_v):
+    """BASELINE configs[4]'s extra terms (build-defined, oracle first): XSPH advection and the
+    cohesion force, in the fused WCSPH step and in the PCISPH step."""
+    from dieselfluid_amd import scenes
+    n3 = 12
+    p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+    p.xsph_eps = 0.25
+    p.st_kappa = 40.0
+    p.pci_max_iters = 3
+    p.delta = 2.0e-7
+    vel = helpers.seeded_velocities(n3 ** 3, 0.5)
+    frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (n3 ** 3, 1))
+    eng = _engine(p)
+    eng.upload("positions", pos)
+    eng.upload("velocities", vel)
+    eng.upload("forces", frc)
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel, force=frc)
+    ora.delta = p.delta
+    # the terms must matter in this set-up, otherwise the test proves nothing
+    p0, _ = scenes.dambreak_scene(n3, math_mode=math_mode)
+    p0.pci_max_iters, p0.delta = 3, 2.0e-7
+    ref0 = po.OracleSPH.from_state(helpers.oracle_params(p0), pos, vel=vel, force=frc)
+    ref0.delta = p0.delta
+    if method == "wcsph":
+        eng.wcsph_step(5); ora.wcsph_step(5); ref0.wcsph_step(5)
+    else:
+        eng.pcisph_begin(); ora.pcisph_begin(); ref0.pcisph_begin()
+        eng.pcisph_step(3); ora.pcisph_step(3); ref0.pcisph_step(3)
+    assert helpers.rel_err(ref0.positions(), ora.positions()) > 50 * tol_x
+    assert helpers.rel_err(eng.download("positions"), ora.positions()) < tol_x
+    assert helpers.rel_err(eng.download("velocities"), ora.velocities(), floor=1e-2) < tol_v
+
+
 def test_upload_download_roundtrip_after_sort():
     """P: buffers keep the reference's host order across the device's re-sorting."""
     p, pos, vel = _reference_system(8, EXACT)
