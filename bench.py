@@ -114,7 +114,7 @@ def main():
             p.delta = 1.0e-7
         if args.extra_terms:
             p.xsph_eps = 0.25
-            p.st_kappa = 10.0
+            p.st_kappa = 25.0 * p.h * p.h  # cohesion acceleration ~ kappa/h^2: keep it resolution independent
         eng = SPHEngine(p, device=local_rank)
         eng.upload("positions", pos)
         eng.reset_forces()
@@ -153,6 +153,12 @@ def main():
         dt = float(t.item())
 
     eng = engines[0]
+    overflow = 0
+    if world > 1:  # a band or capacity overflow would silently drop particles: make it visible
+        ov = torch.tensor([eng.slab_overflow()], dtype=torch.int64,
+                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ov, op=dist.ReduceOp.MAX)
+        overflow = int(ov.item())
     ms_d, n_d = eng.timing("density")
     ms_f, n_f = eng.timing("force_integrate")
     n_local = eng.n
@@ -220,6 +226,7 @@ def main():
                             if args.method == "wcsph" else
                             ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
                              "pci_predict", "pci_density", "update"))},
+            "slab_overflow": overflow,
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,
         }
