@@ -334,8 +334,11 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       }
       rho[g] = acc;
       nmask[(size_t)9 * mstride + g] = mvalid;
+      // An isolated particle (rho = 0) has no neighbour for which the reference would ever form
+      // P/rho^2 (sph_field.go:183-199 only does so inside the j != i loop); the masked sweeps do
+      // visit the particle itself, so its own term has to be a harmless 0 rather than 0/0.
       const float pr = tait_eos<true>(c, acc, c.eos_d0_grad);
-      pterm[g] = dsl_div<true>(pr, acc * acc);
+      pterm[g] = acc > 0.0f ? dsl_div<true>(pr, acc * acc) : 0.0f;
     }
   }
 }
@@ -391,7 +394,9 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
             float4 a = make_float4(kFar, kFar, kFar, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (real) {
               a = make_float4(o[0], o[1], o[2], o[3]);
-              if constexpr (WANT_V || WANT_XS) b = make_float4(o[4], o[5], o[6], __builtin_amdgcn_rcpf(o[7]));
+              // 1/rho = 0 for an isolated particle (rho = 0): it only ever meets itself
+              if constexpr (WANT_V || WANT_XS)
+                b = make_float4(o[4], o[5], o[6], o[7] > 0.0f ? __builtin_amdgcn_rcpf(o[7]) : 0.0f);
             }
             A[slot] = a;
             if constexpr (WANT_V || WANT_XS) B[slot] = b;
