@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--extra-terms", action="store_true",
                     help="BASELINE configs[4]: add the build-defined XSPH + cohesion (surface tension) terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the whole force pass")
     ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -127,7 +128,8 @@ def main():
         engines = [eng]
     else:
         from dieselfluid_amd import slab
-        drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank)
+        drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank,
+                                       overlap=False if args.no_overlap else None)
         step = drv.wcsph_step
         engines = [drv.engine_core]
 
@@ -153,14 +155,18 @@ def main():
         dt = float(t.item())
 
     eng = engines[0]
-    overflow = 0
-    if world > 1:  # a band or capacity overflow would silently drop particles: make it visible
-        ov = torch.tensor([eng.slab_overflow()], dtype=torch.int64,
+    overflow = band_missed = 0
+    if world > 1:
+        # a band / capacity overflow or an outrun split margin would silently lose ghosts: make it visible
+        st4 = eng.slab_status()
+        ov = torch.tensor([st4[0], st4[1]], dtype=torch.int64,
                           device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ov, op=dist.ReduceOp.MAX)
-        overflow = int(ov.item())
+        overflow, band_missed = int(ov[0].item()), int(ov[1].item())
     ms_d, n_d = eng.timing("density")
     ms_f, n_f = eng.timing("force_integrate")
+    if n_f > args.steps:  # split force pass: two launches per step, quote the pass
+        ms_f = ms_f * n_f / args.steps
     n_local = eng.n
     if args.method == "pcisph":
         ms_f = eng.timing("pci_density")[0]  # dominant PCISPH kernel: predicted density, 20 B/particle
@@ -227,6 +233,8 @@ def main():
                             ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
                              "pci_predict", "pci_density", "update"))},
             "slab_overflow": overflow,
+            "slab_band_missed": band_missed,
+            "slab_overlap": bool(world > 1 and drv.overlap),
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,
         }

@@ -92,8 +92,13 @@ EXPORTS = {
     "dsl_download_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_download_cell_start": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_slab_config": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float]),
-    "dsl_slab_pack": (C.c_int, [_vp, C.c_float, _vp, _vp, C.c_int]),
-    "dsl_slab_append": (C.c_int, [_vp, _vp, C.c_int]),
+    "dsl_slab_message_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "dsl_slab_split": (C.c_int, [_vp, C.c_float, C.c_float]),
+    "dsl_slab_pack": (C.c_int, [_vp, C.c_float, C.c_float, _vp, _vp, C.c_int, C.c_int]),
+    "dsl_slab_pack_band": (C.c_int, [_vp, C.c_float, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "dsl_force_pass_split": (C.c_int, [_vp, C.c_int]),
+    "dsl_slab_append": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "dsl_slab_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
     "dsl_slab_overflow": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dsl_get_count": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dsl_set_ids": (C.c_int, [_vp, _ip, C.c_size_t]),

@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -41,7 +42,14 @@ struct dsl_handle {
   int n = 0, cap = 0, ncell = 0, ncell_pad = 0, nscan = 0;
   bool ids_global = false;  // dsl_set_ids replaced the host-order map
   int* dcounter = nullptr;
-  int* dn = nullptr;  // slab mode: [0] live particle count, [1],[2] band counters, [3] overflow high-water mark
+  // slab mode: [0] live particle count, [1..4] band counters (lo/hi full, lo/hi position-only),
+  // [5] overflow high-water mark, [6],[7] largest full / position-only band counts seen
+  int* dn = nullptr;
+  int* pack_counts = nullptr;  // band selection: per-block record counts, then offsets (kernels_grid.hpp)
+  // split slab step (dsl_force_pass_split): band tiles first, interior tiles after the pack
+  float split_margin = 0.0f, split_width = 0.0f;
+  bool split_pending = false;
+  hipEvent_t ev_band = nullptr;
   // DSL_NEIGH_LSH_REF
   bool lsh = false;
   int lsh_bits = 0, lsh_cap = 0;
@@ -97,6 +105,7 @@ int fail(dsl_handle* h, int code, const std::string& msg) {
   } while (0)
 
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
+void update_split(dsl_handle* h);
 // number of slots a per-particle launch has to cover: exact without slabs; in slab mode the
 // live count lives on the device, so cover the whole capacity (idle blocks exit at once)
 inline int launch_n(const dsl_handle* h);
@@ -167,6 +176,13 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   c.slab_axis = -1;
   c.slab_lo = -INFINITY;
   c.slab_hi = INFINITY;
+  c.chk_lo = -INFINITY;
+  c.chk_hi = INFINITY;
+  c.split_cl = 0;
+  c.split_ch = INT_MAX;
+  c.split_part = 0;
+  c.own_c0 = 0;
+  c.own_c1 = INT_MAX;
   c.n_ptr = nullptr;
   return DSL_OK;
 }
@@ -277,6 +293,7 @@ int build_lsh(dsl_handle* h) {
 }
 
 int build_grid(dsl_handle* h, bool carry_derived) {
+  if (h->split_pending) return fail(h, DSL_ERR_INVALID, "a split force pass is in flight: finish it with DSL_SPLIT_INNER");
   if (h->lsh) return build_lsh(h);
   const int n = launch_n(h);
   h->masks_valid = false;  // slot order changes
@@ -347,7 +364,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (h->pci_active) h->cur_pci ^= 1;
   h->grid_valid = true;
   if (h->prm.math_mode == DSL_MATH_FAST) {
-    HIP_TRY(h, hipMemsetAsync(h->n_tiles, 0, sizeof(int), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->n_tiles, 0, 8 * sizeof(int), h->stream));
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
                          h->cell_start, h->tiles, h->n_tiles);
@@ -410,8 +427,24 @@ int density_pass(dsl_handle* h) {
   return DSL_OK;
 }
 
-int force_integrate(dsl_handle* h) {
-  const DevConsts& c = h->c;
+// part 0: every tile, then the state flips to the integrated arrays.  Split slab step:
+// part 1 = band tiles only (state unchanged, dsl_slab_pack_band reads the output arrays next),
+// part 2 = the remaining tiles, then the flip.
+int force_integrate(dsl_handle* h, int part = 0) {
+  DevConsts c = h->c;
+  c.split_part = part;
+  if (part == 2) {  // an interior particle that reaches a packed band moved further than the margin
+    c.chk_lo = c.slab_lo + h->split_width;
+    c.chk_hi = c.slab_hi - h->split_width;
+  }
+  // tile lists (k_tile_list): single domain 0; slab mode 4 = owning tiles (1 / 2 for the split
+  // step's band / interior launch) plus 3 = ghost-only tiles, visited by one launch per step
+  const bool slab = c.slab_axis >= 0;
+  const int la = !slab ? 0 : (part == 0 ? 4 : part);
+  const int* tiles = h->tiles + (size_t)la * h->tg.ntiles;
+  const int* n_tiles = h->n_tiles + la;
+  const int* gtiles = (slab && part != 2) ? h->tiles + (size_t)3 * h->tg.ntiles : nullptr;
+  const int* n_gtiles = h->n_tiles + 3;
   CSoa3 p = cpos(h), v = cvel(h), f = cfrc(h);
   const int o = h->cur_pv ^ 1;
   Soa3 po = mpos(h, o), vo = mvel(h, o);
@@ -421,26 +454,28 @@ int force_integrate(dsl_handle* h) {
   if (use_tiled(h)) {
     rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
       dim3 g(persistent_grid(h, 2)), b(kTBlock);
-#define DSL_LAUNCH_FT(GG, VV)                                                                                   \
-  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tiles, h->n_tiles,    \
-                     h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats,                         \
-                     h->masks_valid ? h->nmask : nullptr, h->cap)
-#define DSL_LAUNCH_FTX(GG, VV)                                                                                  \
-  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, true>), g, b, 0, h->stream, c, h->tg,     \
-                     h->tiles, h->n_tiles, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, h->dstats,   \
-                     h->masks_valid ? h->nmask : nullptr, h->cap)
+#define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                                                           \
+  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS>), g, b, 0, h->stream, c, h->tg,   \
+                     tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo,  \
+                     h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap)
+#define DSL_LAUNCH_FT2(GG, VV, XX)                     \
+  do {                                                \
+    if (c.slab_axis >= 0) DSL_LAUNCH_FT3(GG, VV, XX, true); \
+    else DSL_LAUNCH_FT3(GG, VV, XX, false);           \
+  } while (0)
+#define DSL_LAUNCH_FT(GG, VV)                 \
+  do {                                        \
+    if (XS) DSL_LAUNCH_FT2(GG, VV, true);     \
+    else DSL_LAUNCH_FT2(GG, VV, false);       \
+  } while (0)
       const bool XS = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
-      if (XS) {
-        if (G && V) DSL_LAUNCH_FTX(true, true);
-        else if (G) DSL_LAUNCH_FTX(true, false);
-        else if (V) DSL_LAUNCH_FTX(false, true);
-        else DSL_LAUNCH_FTX(false, false);
-      } else if (G && V) DSL_LAUNCH_FT(true, true);
+      if (G && V) DSL_LAUNCH_FT(true, true);
       else if (G) DSL_LAUNCH_FT(true, false);
       else if (V) DSL_LAUNCH_FT(false, true);
       else DSL_LAUNCH_FT(false, false);
+#undef DSL_LAUNCH_FT3
+#undef DSL_LAUNCH_FT2
 #undef DSL_LAUNCH_FT
-#undef DSL_LAUNCH_FTX
     });
   } else
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
@@ -458,6 +493,7 @@ int force_integrate(dsl_handle* h) {
     });
   });
   if (rc) return rc;
+  if (part == 1) return DSL_OK;
   h->cur_pv = o;
   h->masks_valid = false;    // positions moved
   h->forces_uniform = true;  // Update resets every force to force_reset (fluid.go:193)
@@ -572,6 +608,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->dstats);
   (void)hipFree(h->dcounter);
   (void)hipFree(h->dn);
+  (void)hipFree(h->pack_counts);
   (void)hipFree(h->tiles);
   (void)hipFree(h->n_tiles);
   (void)hipFree(h->hashv);
@@ -586,6 +623,7 @@ void free_all(dsl_handle* h) {
       (void)hipEventDestroy(pr.first);
       (void)hipEventDestroy(pr.second);
     }
+  if (h->ev_band) (void)hipEventDestroy(h->ev_band);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -697,7 +735,8 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
-      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 4)))
+      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 16)) ||
+      (rc = dev_alloc(h, &h->pack_counts, (size_t)4 * ((n + kPackChunk - 1) / kPackChunk))))
     return bail(rc);
   h->lsh = params->neigh_mode == DSL_NEIGH_LSH_REF;
   if (h->lsh) {
@@ -718,7 +757,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
-  if ((rc = dev_alloc(h, &h->tiles, (size_t)h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 4))) return bail(rc);
+  if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
   if (h->prm.math_mode == DSL_MATH_FAST && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
@@ -777,6 +816,10 @@ int dsl_set_params(dsl_handle* h, const dsl_params* p) {
   c.slab_lo = h->c.slab_lo;
   c.slab_hi = h->c.slab_hi;
   c.n_ptr = h->c.n_ptr;
+  c.split_cl = h->c.split_cl;
+  c.split_ch = h->c.split_ch;
+  c.own_c0 = h->c.own_c0;
+  c.own_c1 = h->c.own_c1;
   if (std::memcmp(c.reset, h->c.reset, sizeof(c.reset)) != 0 && h->forces_uniform) {
     if (int rc = materialise_forces(h)) return rc;  // keep the old implicit value
   }
@@ -1200,17 +1243,17 @@ int dsl_pcisph_step(dsl_handle* h, int nsteps) {
       int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45 (+ cohesion, XSPH sums)
         if (XS)
           hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
-                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
                              h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
         else
           hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
-                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
                              h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
       });
       if (rc) return rc;
       rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
         hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
-                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, h->cell_start, p, v, h->rho,
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
                            h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
       });
       if (rc) return rc;
@@ -1265,7 +1308,7 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
   h->c.slab_lo = axis < 0 ? -INFINITY : lo;
   h->c.slab_hi = axis < 0 ? INFINITY : hi;
   if (axis >= 0) {
-    const int init[4] = {ncur, 0, 0, 0};
+    const int init[16] = {ncur};
     HIP_TRY(h, hipMemcpyAsync(h->dn, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->c.n_ptr = h->dn;
@@ -1273,34 +1316,154 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
     h->c.n_ptr = nullptr;
     h->c.n = ncur;
   }
+  update_split(h);
   h->grid_valid = false;
   return DSL_OK;
 }
 
-int dsl_slab_pack(dsl_handle* h, float width, float* dev_lo, float* dev_hi, int capacity) {
+size_t dsl_slab_message_floats(int cap_full, int cap_xonly) {
+  if (cap_full < 0 || cap_xonly < 0) return 0;
+  return (size_t)(cap_full + 1) * kRecord + (size_t)cap_xonly * kRecordX;
+}
+
+namespace {
+// band cell layers: every cell that reaches within width + margin of a slab plane
+void update_split(dsl_handle* h) {
+  DevConsts& c = h->c;
+  c.split_cl = 0;
+  c.split_ch = INT_MAX;
+  c.own_c0 = 0;
+  c.own_c1 = INT_MAX;
+  if (c.slab_axis < 0) return;
+  const int a = c.slab_axis;
+  // Cell layers that can hold owned particles.  A plane that coincides with a cell plane counts as
+  // exact (1e-3 cell of slack): an owned particle that float rounding leaves in a ghost-only tile is
+  // still integrated correctly, through the global-memory sweep (k_force_integrate_tiled).
+  if (std::isfinite(c.slab_lo)) {
+    const float f = std::floor((c.slab_lo - c.gmin[a]) * c.inv_cell + 1.0e-3f);
+    c.own_c0 = f <= 0.0f ? 0 : (f >= (float)c.dims[a] ? c.dims[a] : (int)f);
+  }
+  if (std::isfinite(c.slab_hi)) {
+    const float f = std::ceil((c.slab_hi - c.gmin[a]) * c.inv_cell - 1.0e-3f);
+    c.own_c1 = f <= 0.0f ? 0 : (f >= (float)c.dims[a] ? c.dims[a] : (int)f);
+  }
+  if (!(h->split_width > 0.0f)) return;
+  const float reach = h->split_width + h->split_margin;
+  if (std::isfinite(c.slab_lo)) {
+    // (1e-3 cell of slack: a reach that ends on a cell plane must not spill into the next layer)
+    const float f = std::ceil((c.slab_lo + reach - c.gmin[a]) * c.inv_cell - 1.0e-3f);
+    c.split_cl = f <= 0.0f ? 0 : (f >= (float)c.dims[a] ? c.dims[a] : (int)f);
+  }
+  if (std::isfinite(c.slab_hi)) {
+    const float f = std::floor((c.slab_hi - reach - c.gmin[a]) * c.inv_cell + 1.0e-3f);
+    c.split_ch = f <= 0.0f ? 0 : (f >= (float)c.dims[a] ? c.dims[a] : (int)f);
+  } else {
+    c.split_ch = c.dims[a];
+  }
+  if (c.split_ch < c.split_cl) c.split_ch = c.split_cl;  // thin slab: every layer is a band layer
+}
+}  // namespace
+
+int dsl_slab_split(dsl_handle* h, float width, float margin) {
   CHECK_HANDLE(h);
-  if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: no slab configured");
-  if ((!dev_lo && !dev_hi) || capacity < 0 || !(width >= 0.0f)) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: bad argument");
-  HIP_TRY(h, hipMemsetAsync(h->dn + 1, 0, 2 * sizeof(int), h->stream));
-  CSoa3 p = cpos(h), v = cvel(h);
-  hipLaunchKernelGGL(k_slab_pack, dim3(grid_for(h->cap)), dim3(kBlock), 0, h->stream, h->c, h->c.slab_lo + width,
-                     h->c.slab_hi - width, dev_lo ? 1 : 0, dev_hi ? 1 : 0, p.x, p.y, p.z, v.x, v.y, v.z,
-                     h->ids[h->cur_ids], dev_lo, dev_hi, capacity, h->dn + 1);
-  hipLaunchKernelGGL(k_slab_header, dim3(1), dim3(1), 0, h->stream, h->dn + 1, dev_lo, dev_hi, capacity, h->dn + 3);
-  HIP_TRY(h, hipGetLastError());
+  if (!(width >= 0.0f) || !(margin >= 0.0f)) return fail(h, DSL_ERR_INVALID, "dsl_slab_split: bad width or margin");
+  if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_slab_split: a split force pass is in flight");
+  h->split_width = width;
+  h->split_margin = margin;
+  update_split(h);
+  h->grid_valid = false;  // the band / interior tile lists are made by the neighbour build
   return DSL_OK;
 }
 
-int dsl_slab_append(dsl_handle* h, const float* dev_message, int capacity) {
+namespace {
+int slab_pack_on(dsl_handle* h, hipStream_t st, float width_full, float width, bool from_output, float* dev_lo,
+                 float* dev_hi, int cap_full, int cap_x) {
+  SlabBands sb;
+  sb.full_lo = h->c.slab_lo + width_full;
+  sb.band_lo = h->c.slab_lo + width;
+  sb.full_hi = h->c.slab_hi - width_full;
+  sb.band_hi = h->c.slab_hi - width;
+  CSoa3 p = cpos(h), v = cvel(h);
+  const float* old_axis = nullptr;
+  if (from_output) {  // band phase of the split step: integrated values are in the other half
+    old_axis = h->c.slab_axis == 0 ? p.x : (h->c.slab_axis == 1 ? p.y : p.z);
+    Soa3 po = mpos(h, h->cur_pv ^ 1), vo = mvel(h, h->cur_pv ^ 1);
+    p = CSoa3{po.x, po.y, po.z};
+    v = CSoa3{vo.x, vo.y, vo.z};
+  }
+  const float* pa = h->c.slab_axis == 0 ? p.x : (h->c.slab_axis == 1 ? p.y : p.z);
+  const int nblk = (h->cap + kPackChunk - 1) / kPackChunk;
+  hipLaunchKernelGGL(k_slab_count, dim3(nblk), dim3(kBlock), 0, st, h->c, sb, old_axis, pa, dev_lo ? 1 : 0,
+                     dev_hi ? 1 : 0, h->pack_counts);
+  hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(kOffsBlock), 0, st, h->pack_counts, nblk, dev_lo, dev_hi, cap_full,
+                     cap_x, h->dn + 5);
+  hipLaunchKernelGGL(k_slab_write, dim3(nblk), dim3(kBlock), 0, st, h->c, sb, old_axis, pa, p.x, p.y, p.z, v.x, v.y, v.z,
+                     h->ids[h->cur_ids], dev_lo, dev_hi, cap_full, cap_x, h->pack_counts);
+  HIP_TRY(h, hipGetLastError());
+  return DSL_OK;
+}
+int slab_pack_check(dsl_handle* h, const char* who, float width_full, float width, float* dev_lo, float* dev_hi,
+                    int cap_full, int cap_x) {
+  if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, std::string(who) + ": no slab configured");
+  if ((!dev_lo && !dev_hi) || cap_full < 0 || cap_x < 0 || !(width_full >= 0.0f) || !(width >= width_full))
+    return fail(h, DSL_ERR_INVALID, std::string(who) + ": bad argument");
+  return DSL_OK;
+}
+}  // namespace
+
+int dsl_slab_pack(dsl_handle* h, float width_full, float width, float* dev_lo, float* dev_hi, int cap_full,
+                  int cap_xonly) {
+  CHECK_HANDLE(h);
+  if (int rc = slab_pack_check(h, "dsl_slab_pack", width_full, width, dev_lo, dev_hi, cap_full, cap_xonly)) return rc;
+  if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_slab_pack: a split force pass is in flight");
+  return slab_pack_on(h, h->stream, width_full, width, false, dev_lo, dev_hi, cap_full, cap_xonly);
+}
+
+int dsl_slab_pack_band(dsl_handle* h, float width_full, float* dev_lo, float* dev_hi, int cap_full, int cap_xonly,
+                       void* stream) {
+  CHECK_HANDLE(h);
+  if (int rc = slab_pack_check(h, "dsl_slab_pack_band", width_full, h->split_width, dev_lo, dev_hi, cap_full, cap_xonly))
+    return rc;
+  if (!h->split_pending)
+    return fail(h, DSL_ERR_INVALID, "dsl_slab_pack_band: call dsl_force_pass_split(DSL_SPLIT_BAND) first");
+  hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  if (st != h->stream) HIP_TRY(h, hipStreamWaitEvent(st, h->ev_band, 0));
+  return slab_pack_on(h, st, width_full, h->split_width, true, dev_lo, dev_hi, cap_full, cap_xonly);
+}
+
+int dsl_force_pass_split(dsl_handle* h, int phase) {
+  CHECK_HANDLE(h);
+  if (phase == DSL_SPLIT_BAND) {
+    if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_force_pass_split: band phase already done");
+    if (!h->c.n_ptr || !(h->split_width > 0.0f))
+      return fail(h, DSL_ERR_INVALID, "dsl_force_pass_split: needs dsl_slab_config and dsl_slab_split");
+    if (!use_tiled(h)) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_force_pass_split: needs the tiled kernels (DSL_MATH_FAST)");
+    if (int rc = ensure_grid(h)) return rc;
+    if (!h->ev_band) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_band, hipEventDisableTiming));
+    if (int rc = force_integrate(h, 1)) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_band, h->stream));
+    h->split_pending = true;
+    return DSL_OK;
+  }
+  if (phase == DSL_SPLIT_INNER) {
+    if (!h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_force_pass_split: band phase missing");
+    h->split_pending = false;
+    return force_integrate(h, 2);
+  }
+  return fail(h, DSL_ERR_INVALID, "dsl_force_pass_split: bad phase");
+}
+
+int dsl_slab_append(dsl_handle* h, const float* dev_message, int cap_full, int cap_xonly) {
   CHECK_HANDLE(h);
   if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: no slab configured");
-  if (!dev_message || capacity < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
+  if (!dev_message || cap_full < 0 || cap_xonly < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
+  if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: a split force pass is in flight");
   if (!h->forces_uniform) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: forces must be uniform (dsl_reset_forces)");
-  if (capacity == 0) return DSL_OK;
+  if (cap_full + cap_xonly == 0) return DSL_OK;
   Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
-  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(capacity)), dim3(kBlock), 0, h->stream, dev_message, capacity, h->dn,
-                     h->cap, p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], h->dn + 3);
-  hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message, capacity, h->dn, h->cap);
+  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(cap_full + cap_xonly)), dim3(kBlock), 0, h->stream, dev_message,
+                     cap_full, cap_xonly, h->dn, h->cap, p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], h->dn + 5);
+  hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message, cap_full, cap_xonly, h->dn, h->cap);
   HIP_TRY(h, hipGetLastError());
   h->grid_valid = false;
   h->dens_fresh = false;
@@ -1317,8 +1480,7 @@ int dsl_get_count(dsl_handle* h, int* n_live, int* n_owned) {
     if (h->c.slab_axis >= 0 && ncur > 0) {
       HIP_TRY(h, hipMemsetAsync(h->dcounter, 0, sizeof(int), h->stream));
       CSoa3 p = cpos(h);
-      hipLaunchKernelGGL(k_count_owned, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, h->c, p.x, p.y, p.z,
-                         h->dcounter);
+      hipLaunchKernelGGL(k_count_owned, dim3(1024), dim3(kBlock), 0, h->stream, h->c, p.x, p.y, p.z, h->dcounter);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipMemcpyAsync(n_owned, h->dcounter, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1327,14 +1489,28 @@ int dsl_get_count(dsl_handle* h, int* n_live, int* n_owned) {
   return DSL_OK;
 }
 
-int dsl_slab_overflow(dsl_handle* h, int* high_water) {
+int dsl_slab_status(dsl_handle* h, int32_t status[4], int reset_high_water) {
   CHECK_HANDLE(h);
-  int v = 0;
+  if (!status) return fail(h, DSL_ERR_INVALID, "dsl_slab_status: null output");
+  int st[3] = {0, 0, 0};
+  int missed = 0;
   if (h->c.n_ptr) {
-    HIP_TRY(h, hipMemcpyAsync(&v, h->dn + 3, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(st, h->dn + 5, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&missed, &h->dstats->band_missed, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (reset_high_water) HIP_TRY(h, hipMemsetAsync(h->dn + 6, 0, 2 * sizeof(int), h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
-  if (high_water) *high_water = v;
+  status[0] = st[0];
+  status[1] = missed;
+  status[2] = st[1];
+  status[3] = st[2];
+  return DSL_OK;
+}
+
+int dsl_slab_overflow(dsl_handle* h, int* high_water) {
+  int32_t st[4] = {0, 0, 0, 0};
+  if (int rc = dsl_slab_status(h, st, 0)) return rc;
+  if (high_water) *high_water = st[0];
   return DSL_OK;
 }
 

@@ -19,10 +19,11 @@ constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lan
 // same cell (the input is the previous step's sorted order), so equal-cell runs are
 // found with one ballot and only the run's first lane issues the atomic.
 // ---------------------------------------------------------------------------------
-// Slab mode: stale ghosts carry NaN positions (written by the integrate kernels); they go
-// to the extra bucket `ncell` and so sort behind every live particle.  A particle that has
-// just crossed the slab plane stays finite: it serves as a ghost for one more step, because
-// the neighbour packed its own band before receiving it.
+// Slab mode: stale ghosts carry NaN positions (written by the integrate kernels); they get the
+// pseudo cell `ncell`, are not counted and are not scattered, so the sorted arrays hold the live
+// particles only (cell_start[ncell] = their number).  A particle that has just crossed the
+// slab plane stays finite: it serves as a ghost for one more step, because the neighbour
+// packed its own band before receiving it.
 __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* __restrict__ px,
                                                       const float* __restrict__ py,
                                                       const float* __restrict__ pz, int* __restrict__ cellid,
@@ -48,7 +49,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   const int next = above ? __builtin_ctzll(above) : kWave;
   const int run = next - head_lane;
   int base = 0;
-  if (lane == head_lane && cell >= 0) base = atomicAdd(&cell_count[cell], run);
+  // (a whole band of stale ghosts would otherwise hammer one counter: same-address atomics serialise)
+  if (lane == head_lane && cell >= 0 && cell != c.ncell) base = atomicAdd(&cell_count[cell], run);
   base = __shfl(base, head_lane, kWave);
   if (i < n) {
     cellid[i] = cell;
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
                                                     const int* __restrict__ cell_start) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
+  if (cellid[i] == c.ncell) return;  // stale ghost: dropped
   const int d = cell_start[cellid[i]] + rank[i];
   a.ids_dst[d] = a.ids_src[i];
   for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
@@ -208,108 +211,279 @@ __global__ __launch_bounds__(kBlock) void k_pack1(int n, float* __restrict__ sta
 // ---------------------------------------------------------------------------------
 // slab halo: band selection (wave-aggregated append) and record append
 // ---------------------------------------------------------------------------------
-constexpr int kRecord = 7;  // x,y,z,vx,vy,vz,id-bits
+constexpr int kRecord = 7;   // full record: x,y,z,vx,vy,vz,id-bits
+constexpr int kRecordX = 3;  // position-only record: x,y,z
 
-// Message layout: record 0 is a header whose first word holds the record count (int bits);
-// records 1..count follow.  Both bands are selected in one pass; counters[side] counts.
-__global__ __launch_bounds__(kBlock) void k_slab_pack(DevConsts c, float bound_lo, float bound_hi, int want_lo,
-                                                      int want_hi, const float* __restrict__ px,
-                                                      const float* __restrict__ py, const float* __restrict__ pz,
-                                                      const float* __restrict__ vx, const float* __restrict__ vy,
-                                                      const float* __restrict__ vz, const int* __restrict__ ids,
-                                                      float* __restrict__ out_lo, float* __restrict__ out_hi,
-                                                      int capacity, int* __restrict__ counters) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
-  bool take[2] = {false, false};
-  float x = 0.f, y = 0.f, z = 0.f;
-  if (i < live_n(c)) {
-    x = px[i];
-    y = py[i];
-    z = pz[i];
-    const float p = c.slab_axis == 0 ? x : (c.slab_axis == 1 ? y : z);
-    const bool finite = (x == x) && (y == y) && (z == z);  // ghosts carry NaN after the step
-    take[0] = want_lo && finite && (p < bound_lo);
-    take[1] = want_hi && finite && (p >= bound_hi);
-  }
+// Message layout (floats): header of kRecord words ([0] = full-record count, [1] =
+// position-only count, int bits), cap_full full records, cap_x position-only records.
+// Particles within width_full of the plane (and migrants beyond it) travel as full records;
+// the rest of the band only feeds the receiver's ghost densities and travels as positions.
+struct SlabBands {
+  float full_lo, band_lo;  // lo side: p < full_lo -> full record, else p < band_lo -> position only
+  float full_hi, band_hi;  // hi side: p >= full_hi -> full record, else p >= band_hi -> position only
+};
+__device__ __forceinline__ float* slab_full_record(float* msg, int k) { return msg + (size_t)(k + 1) * kRecord; }
+__device__ __forceinline__ float* slab_x_record(float* msg, int cap_full, int k) {
+  return msg + (size_t)(cap_full + 1) * kRecord + (size_t)k * kRecordX;
+}
+
+// Band selection without atomics (a band is a contiguous slot range in cell order, so per-wave
+// atomics on four counters would all collide: same-address atomics serialise): every block
+// of kPackChunk slots counts its records per category, one block turns the counts into offsets
+// and writes the headers, then the same blocks write their records at those offsets.  The
+// message order is the slot order.
+// Categories: [0] lo full, [1] hi full, [2] lo position-only, [3] hi position-only.
+// `old_axis` (may be null) is the slab-axis coordinate array BEFORE the integration that wrote
+// px..vz: with it only the particles of the band cell layers are looked at, which is what lets the
+// pack run while the interior tiles are still being integrated (their new entries are not read).
+constexpr int kPackIters = 8;
+constexpr int kPackChunk = kBlock * kPackIters;  // slots per block; wave w owns kPackIters x 64 consecutive ones
+
+// bit (4*it + k) of the result: slot (base + it*64 + lane) belongs to category k
+__device__ __forceinline__ unsigned int slab_classify(const DevConsts& c, const SlabBands& sb,
+                                                      const float* __restrict__ old_axis,
+                                                      const float* __restrict__ pa, bool want_lo, bool want_hi,
+                                                      int base, int lane, int n) {
+  unsigned int flags = 0u;
 #pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    const unsigned long long m = __ballot(take[side]);
-    if (m == 0ull) continue;
-    const int leader = __builtin_ctzll(m);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&counters[side], __builtin_popcountll(m));
-    base = __shfl(base, leader, kWave);
-    if (take[side]) {
-      const int d = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      if (d < capacity) {
-        float* r = (side == 0 ? out_lo : out_hi) + (size_t)(d + 1) * kRecord;
-        r[0] = x;
-        r[1] = y;
-        r[2] = z;
-        r[3] = vx[i];
-        r[4] = vy[i];
-        r[5] = vz[i];
-        r[6] = __int_as_float(ids[i]);
-      }
+  for (int it = 0; it < kPackIters; ++it) {
+    const int i = base + it * kWave + lane;
+    bool look = i < n;
+    if (look && old_axis) {
+      const int a = c.slab_axis;
+      look = slab_band_cell(c, cell_coord(old_axis[i], c.gmin[a], c.inv_cell, c.dims[a]));
     }
+    if (!look) continue;
+    const float p = pa[i];  // NaN (a ghost of the step that has just been integrated) fails every test
+    unsigned int f = 0u;
+    if (want_lo) f |= p < sb.full_lo ? 1u : (p < sb.band_lo ? 4u : 0u);
+    if (want_hi) f |= p >= sb.full_hi ? 2u : (p >= sb.band_hi ? 8u : 0u);
+    flags |= f << (4 * it);
   }
+  return flags;
 }
-// header = min(count, capacity); an overflow is recorded for the host to find later
-__global__ void k_slab_header(const int* __restrict__ counters, float* out_lo, float* out_hi, int capacity,
-                              int* __restrict__ overflow) {
-  for (int side = 0; side < 2; ++side) {
-    float* o = side == 0 ? out_lo : out_hi;
-    if (!o) continue;
-    int n = counters[side];
-    if (n > capacity) {
-      atomicMax(overflow, n);
-      n = capacity;
-    }
-    o[0] = __int_as_float(n);
+
+__global__ __launch_bounds__(kBlock) void k_slab_count(DevConsts c, SlabBands sb, const float* __restrict__ old_axis,
+                                                       const float* __restrict__ pa, int want_lo, int want_hi,
+                                                       int* __restrict__ block_counts) {
+  __shared__ int wsum[kBlock / kWave][4];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+  const int base = blockIdx.x * kPackChunk + wid * (kPackIters * kWave);
+  const unsigned int flags = slab_classify(c, sb, old_axis, pa, want_lo, want_hi, base, lane, live_n(c));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < kPackIters; ++it) cnt += __builtin_popcountll(__ballot((flags >> (4 * it + k)) & 1u));
+    if (lane == 0) wsum[wid][k] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    int t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += wsum[w][threadIdx.x];
+    block_counts[blockIdx.x * 4 + threadIdx.x] = t;
   }
 }
 
-// appends the records of a message (count in its header) behind the current particles
-__global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg, int capacity,
+// one block: exclusive scan of block_counts (in place) per category, then the two headers;
+// overflows and high-water marks are kept for the host to find later.
+// slab_state: [0] overflow, [1] high water full, [2] high water position-only
+constexpr int kOffsBlock = 1024;
+__global__ __launch_bounds__(kOffsBlock) void k_slab_offsets(int* __restrict__ block_counts, int nblk, float* out_lo,
+                                                             float* out_hi, int cap_full, int cap_x,
+                                                             int* __restrict__ slab_state) {
+  __shared__ int part[kOffsBlock / kWave][4];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+  const int per = (nblk + kOffsBlock - 1) / kOffsBlock;
+  const int b0 = tid * per, b1 = min(b0 + per, nblk);
+  int mine[4] = {0, 0, 0, 0};
+  for (int b = b0; b < b1; ++b)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mine[k] += block_counts[b * 4 + k];
+  int excl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int inc = mine[k];
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const int t = __shfl_up(inc, o, kWave);
+      if (lane >= o) inc += t;
+    }
+    excl[k] = inc - mine[k];
+    if (lane == kWave - 1) part[wid][k] = inc;
+  }
+  __syncthreads();
+  int total[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int before = 0, all = 0;
+    for (int w = 0; w < kOffsBlock / kWave; ++w) {
+      const int v = part[w][k];
+      if (w < wid) before += v;
+      all += v;
+    }
+    excl[k] += before;
+    total[k] = all;
+  }
+  for (int b = b0; b < b1; ++b)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int v = block_counts[b * 4 + k];
+      block_counts[b * 4 + k] = excl[k];
+      excl[k] += v;
+    }
+  if (tid == 0) {
+    for (int side = 0; side < 2; ++side) {
+      float* o = side == 0 ? out_lo : out_hi;
+      if (!o) continue;
+      int nf = total[side], nx = total[2 + side];
+      atomicMax(&slab_state[1], nf);
+      atomicMax(&slab_state[2], nx);
+      if (nf > cap_full) {
+        atomicMax(&slab_state[0], nf);
+        nf = cap_full;
+      }
+      if (nx > cap_x) {
+        atomicMax(&slab_state[0], nx);
+        nx = cap_x;
+      }
+      o[0] = __int_as_float(nf);
+      o[1] = __int_as_float(nx);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_slab_write(DevConsts c, SlabBands sb, const float* __restrict__ old_axis,
+                                                       const float* __restrict__ pa, const float* __restrict__ px,
+                                                       const float* __restrict__ py, const float* __restrict__ pz,
+                                                       const float* __restrict__ vx, const float* __restrict__ vy,
+                                                       const float* __restrict__ vz, const int* __restrict__ ids,
+                                                       float* __restrict__ out_lo, float* __restrict__ out_hi,
+                                                       int cap_full, int cap_x, const int* __restrict__ block_offsets) {
+  __shared__ int wsum[kBlock / kWave][4];
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+  const int base = blockIdx.x * kPackChunk + wid * (kPackIters * kWave);
+  const unsigned int flags = slab_classify(c, sb, old_axis, pa, out_lo != nullptr, out_hi != nullptr, base, lane, live_n(c));
+  unsigned long long bal[4][kPackIters];
+  int cnt[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cnt[k] = 0;
+#pragma unroll
+    for (int it = 0; it < kPackIters; ++it) {
+      bal[k][it] = __ballot((flags >> (4 * it + k)) & 1u);
+      cnt[k] += __builtin_popcountll(bal[k][it]);
+    }
+    if (lane == 0) wsum[wid][k] = cnt[k];
+  }
+  __syncthreads();
+  if ((cnt[0] | cnt[1] | cnt[2] | cnt[3]) == 0) return;  // wave-uniform
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (cnt[k] == 0) continue;
+    int at = block_offsets[blockIdx.x * 4 + k];
+    for (int w = 0; w < wid; ++w) at += wsum[w][k];
+    float* msg = (k & 1) ? out_hi : out_lo;
+#pragma unroll
+    for (int it = 0; it < kPackIters; ++it) {
+      if ((flags >> (4 * it + k)) & 1u) {
+        const int i = base + it * kWave + lane;
+        const int d = at + __builtin_popcountll(bal[k][it] & below);
+        if (k < 2) {
+          if (d < cap_full) {
+            float* r = slab_full_record(msg, d);
+            r[0] = px[i];
+            r[1] = py[i];
+            r[2] = pz[i];
+            r[3] = vx[i];
+            r[4] = vy[i];
+            r[5] = vz[i];
+            r[6] = __int_as_float(ids[i]);
+          }
+        } else if (d < cap_x) {
+          float* r = slab_x_record(msg, cap_full, d);
+          r[0] = px[i];
+          r[1] = py[i];
+          r[2] = pz[i];
+        }
+      }
+      at += __builtin_popcountll(bal[k][it]);
+    }
+  }
+}
+
+__device__ __forceinline__ void slab_counts(const float* msg, int cap_full, int cap_x, int& nf, int& nx) {
+  nf = __float_as_int(msg[0]);
+  nx = __float_as_int(msg[1]);
+  nf = nf < 0 ? 0 : (nf > cap_full ? cap_full : nf);
+  nx = nx < 0 ? 0 : (nx > cap_x ? cap_x : nx);
+}
+
+// appends the records of a message behind the current particles: full records first, then
+// the position-only ones (velocity 0, id -1: they are ghosts by construction)
+__global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg, int cap_full, int cap_x,
                                                         const int* __restrict__ n_cur, int room,
                                                         float* __restrict__ px, float* __restrict__ py,
                                                         float* __restrict__ pz, float* __restrict__ vx,
                                                         float* __restrict__ vy, float* __restrict__ vz,
-                                                        int* __restrict__ ids, int* __restrict__ overflow) {
+                                                        int* __restrict__ ids, int* __restrict__ slab_state) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
-  int count = __float_as_int(msg[0]);
-  count = count < 0 ? 0 : (count > capacity ? capacity : count);
+  int nf, nx;
+  slab_counts(msg, cap_full, cap_x, nf, nx);
   const int at = *n_cur;
-  if (at + count > room) {  // does not fit: record it, append nothing
-    if (k == 0) atomicMax(overflow, at + count);
+  if (at + nf + nx > room) {  // does not fit: record it, append nothing
+    if (k == 0) atomicMax(&slab_state[0], at + nf + nx);
     return;
   }
-  if (k >= count) return;
-  const float* r = msg + (size_t)(k + 1) * kRecord;
-  const int d = at + k;
-  px[d] = r[0];
-  py[d] = r[1];
-  pz[d] = r[2];
-  vx[d] = r[3];
-  vy[d] = r[4];
-  vz[d] = r[5];
-  ids[d] = __float_as_int(r[6]);
+  if (k < nf) {
+    const float* r = msg + (size_t)(k + 1) * kRecord;
+    const int d = at + k;
+    px[d] = r[0];
+    py[d] = r[1];
+    pz[d] = r[2];
+    vx[d] = r[3];
+    vy[d] = r[4];
+    vz[d] = r[5];
+    ids[d] = __float_as_int(r[6]);
+  } else if (k >= cap_full && k - cap_full < nx) {
+    const int j = k - cap_full;
+    const float* r = msg + (size_t)(cap_full + 1) * kRecord + (size_t)j * kRecordX;
+    const int d = at + nf + j;
+    px[d] = r[0];
+    py[d] = r[1];
+    pz[d] = r[2];
+    vx[d] = 0.f;
+    vy[d] = 0.f;
+    vz[d] = 0.f;
+    ids[d] = -1;
+  }
 }
-__global__ void k_slab_bump(const float* __restrict__ msg, int capacity, int* __restrict__ n_cur, int room) {
-  int count = __float_as_int(msg[0]);
-  count = count < 0 ? 0 : (count > capacity ? capacity : count);
-  if (*n_cur + count <= room) *n_cur += count;
+__global__ void k_slab_bump(const float* __restrict__ msg, int cap_full, int cap_x, int* __restrict__ n_cur,
+                            int room) {
+  int nf, nx;
+  slab_counts(msg, cap_full, cap_x, nf, nx);
+  if (*n_cur + nf + nx <= room) *n_cur += nf + nx;
 }
 __global__ void k_set_count(int* __restrict__ n_cur, const int* __restrict__ src) { *n_cur = *src; }
 
 __global__ __launch_bounds__(kBlock) void k_count_owned(DevConsts c, const float* __restrict__ px,
                                                         const float* __restrict__ py, const float* __restrict__ pz,
                                                         int* __restrict__ counter) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  const bool own = i < live_n(c) && slab_owned(c, px[i], py[i], pz[i]);
-  const unsigned long long m = __ballot(own);
-  if ((threadIdx.x & (kWave - 1)) == 0 && m) atomicAdd(counter, __builtin_popcountll(m));
+  __shared__ int wsum[kBlock / kWave];
+  int cnt = 0;
+  const int n = live_n(c);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)  // few blocks: few same-address atomics
+    cnt += slab_owned(c, px[i], py[i], pz[i]) ? 1 : 0;
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) t += wsum[w];
+    if (t) atomicAdd(counter, t);
+  }
 }
 
 // every stride-th particle (by host index) of a 3-component buffer: out[id/stride] = value(id)

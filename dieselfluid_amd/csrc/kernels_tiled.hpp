@@ -15,7 +15,7 @@
 // knows which (q > 0) and emits one 32-bit mask per x-run (9 words per particle, bit order =
 // visit order); the force sweeps then walk only the set bits with the full per-pair
 // arithmetic.  Masks stay valid while positions and slot order do (same step); runs longer
-// than 32 candidates clear the particle's "valid" word and that particle sweeps everything.
+// than 32 candidates clear their bit in the particle's "valid" word and are swept in full.
 //
 // Work distribution: k_tile_list compacts the non-empty tiles (the dam-break box is ~8x
 // larger than the fluid); a persistent grid walks that list, contiguous chunks per XCD so
@@ -28,13 +28,13 @@
 
 namespace dsl {
 
-constexpr int kTB = 4;                 // tile edge in cells
 constexpr int kTH = kTB + 2;           // with halo
 constexpr int kTRows = kTH * kTH;      // 36 staged x-rows
 constexpr int kTBlock = 512;           // threads per tile workgroup (8 waves)
 constexpr int kTPad = 4;               // pad records per staged row (over-read guard)
 constexpr int kTCap = 2304;            // staged records per tile (1.33 x the 1728 of 8 per cell)
 constexpr float kFar = 1.0e15f;        // pad coordinate: finite, far outside any domain
+constexpr int kTileLists = 5;
 constexpr int kMaskWords = 10;         // 9 run masks + 1 valid word per particle (SoA, stride = capacity)
 
 struct TileMeta {
@@ -63,20 +63,47 @@ __device__ unsigned long long g_diag[8];
 // ---------------------------------------------------------------------------------
 // non-empty tile list
 // ---------------------------------------------------------------------------------
+// tiles holds kTileLists lists of tg.ntiles entries each: [0] every non-empty tile; slab mode
+// also [4] the tiles with cell layers this slab owns and [3] the rest (ghosts only: the force
+// pass just marks those for removal), and for the split force pass [1] the owning tiles that
+// contain band cell layers and [2] those that contain other layers (a tile straddling the
+// limit is in both).
 __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                       int* __restrict__ tiles, int* __restrict__ n_tiles) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
-  if (t >= tg.ntiles) return;
-  const int tx = t % tg.tnx, ty = (t / tg.tnx) % tg.tny, tz = t / (tg.tnx * tg.tny);
-  const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
-  const int xa = tx * kTB, xb = min(xa + kTB, nx);
+  const int lane = threadIdx.x & (kWave - 1);
   int cnt = 0;
-  for (int z = tz * kTB; z < min(tz * kTB + kTB, nz); ++z)
-    for (int y = ty * kTB; y < min(ty * kTB + kTB, ny); ++y) {
-      const int row = (z * ny + y) * nx;
-      cnt += cell_start[row + xb] - cell_start[row + xa];
+  bool in_band = false, in_inner = false, owning = false, ghosts = false;
+  if (t < tg.ntiles) {
+    const int tx = t % tg.tnx, ty = (t / tg.tnx) % tg.tny, tz = t / (tg.tnx * tg.tny);
+    const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
+    const int xa = tx * kTB, xb = min(xa + kTB, nx);
+    for (int z = tz * kTB; z < min(tz * kTB + kTB, nz); ++z)
+      for (int y = ty * kTB; y < min(ty * kTB + kTB, ny); ++y) {
+        const int row = (z * ny + y) * nx;
+        cnt += cell_start[row + xb] - cell_start[row + xa];
+      }
+    if (cnt > 0 && c.slab_axis >= 0) {
+      const int a = c.slab_axis, ta = a == 0 ? tx : (a == 1 ? ty : tz);
+      const int a0 = ta * kTB, a1 = min(a0 + kTB, c.dims[a]);
+      owning = max(a0, c.own_c0) < min(a1, c.own_c1);
+      ghosts = !owning;
+      in_band = owning && (a0 < c.split_cl || a1 > c.split_ch);
+      in_inner = owning && max(a0, c.split_cl) < min(a1, c.split_ch);
     }
-  if (cnt > 0) tiles[atomicAdd(n_tiles, 1)] = t;
+  }
+  // one atomic per wave and list (same-address atomics serialise)
+#pragma unroll
+  for (int l = 0; l < kTileLists; ++l) {
+    const bool in = l == 0 ? cnt > 0 : (l == 1 ? in_band : (l == 2 ? in_inner : (l == 3 ? ghosts : owning)));
+    const unsigned long long m = __ballot(in);
+    if (m == 0ull) continue;
+    const int leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(n_tiles + l, __builtin_popcountll(m));
+    base = __shfl(base, leader, kWave);
+    if (in) tiles[(size_t)l * tg.ntiles + base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -165,21 +192,24 @@ __device__ __forceinline__ int b128_group_slot(int lane) {
   return (lane & 32) + 16 * g + idx;
 }
 
-// XCD-aware walk of the tile list: blocks b and b+8 share an XCD (and its L2), so each XCD
-// takes one contiguous eighth of the list.
+// XCD-aware walk of the tile list: blocks b and b+8 share an XCD (and its L2).  The list is dealt
+// to the XCDs in groups of kWalkGroup consecutive tiles (neighbouring tiles share halo rows, so a
+// group mostly hits its XCD's L2), round-robin, so that runs of cheap tiles -- ghost layers,
+// half-empty layers -- do not all land on one XCD.
+constexpr int kWalkGroup = 128;
 struct TileWalk {
-  int chunk, k, kstep, base, n;
+  int li, lstep, lend, xcd, n;
   __device__ __forceinline__ TileWalk(int n_tiles) {
     n = n_tiles;
-    chunk = (n_tiles + 7) >> 3;
-    base = (blockIdx.x & 7) * chunk;
-    k = blockIdx.x >> 3;
-    kstep = (gridDim.x + 7) >> 3;
+    xcd = blockIdx.x & 7;
+    li = blockIdx.x >> 3;
+    lstep = (gridDim.x + 7) >> 3;
+    lend = ((n_tiles + 8 * kWalkGroup - 1) / (8 * kWalkGroup)) * kWalkGroup;  // items an XCD may own
   }
   __device__ __forceinline__ bool next(int& item) {
-    while (k < chunk) {
-      item = base + k;
-      k += kstep;
+    while (li < lend) {
+      item = ((li / kWalkGroup) * 8 + xcd) * kWalkGroup + (li % kWalkGroup);
+      li += lstep;
       if (item < n) return true;
     }
     return false;
@@ -229,6 +259,22 @@ __device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane,
     if (lane < npad) store(ls + len + lane, reg[k], false);
   }
 }
+
+// How the next pass over a tile's targets is shared out (see k_density_tiled): with `rem` targets
+// left, k = 1, 2, 4 or 8 adjacent lanes work on each target; `count` targets are taken.
+struct TargetSplit {
+  int k, sub, target, count;
+  bool active;
+  __device__ __forceinline__ TargetSplit(int rem, int tid, int tperm) {
+    const int shift = rem > kTBlock / 2 ? 0 : (rem > kTBlock / 4 ? 1 : (rem > kTBlock / 8 ? 2 : 3));
+    k = 1 << shift;
+    const int idx = shift == 0 ? tperm : tid;  // the bank-conflict permutation only pays for full passes
+    target = idx >> shift;
+    sub = idx & (k - 1);
+    count = min(rem, kTBlock >> shift);
+    active = target < count;
+  }
+};
 
 // ---------------------------------------------------------------------------------
 // D (tiled): densities + P/rho^2
@@ -280,28 +326,32 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     const int ntarg = m.tprefix[kTB * kTB];
     const int x0 = (tile % tg.tnx) * kTB - 1;
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
-    for (int t = tperm; t < ntarg; t += kTBlock) {
-      int srow, off;
-      tile_target(m, t, srow, off);
-      const int g = m.row_gs[srow] + off;
+    // Targets are taken kTBlock at a time, one lane each.  A tile's LDS slot is held for as long as
+    // its slowest pass, so a short pass -- the few targets beyond kTBlock once the lattice has
+    // melted, or a half-empty tile at a slab end -- is shared out: 2, 4 or 8 adjacent lanes per
+    // target, each sweeping every k-th of the 9 runs, sums combined by shuffles.
+    for (int tbase = 0; tbase < ntarg;) {
+      const TargetSplit ts(ntarg - tbase, tid, tperm);
+      const int t = tbase + ts.target;
+      tbase += ts.count;
+      int g = 0;
       float acc = 0.0f, acc1 = 0.0f;
       unsigned int mvalid = 0u;
-      if (!ovf) {
-        const float4 me = A[m.row_lds[srow] + off];
-        const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
-        const float ninv = -c.inv_hh;
-        const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
-        mvalid = 1u;
-        int ri = 0;
-#pragma unroll 1
-        for (int dz = -kTH; dz <= kTH; dz += kTH) {
-#pragma unroll 1
-          for (int dy = -1; dy <= 1; ++dy, ++ri) {
-            const int rr = srow + dz + dy;
+      if (ts.active) {
+        int srow, off;
+        tile_target(m, t, srow, off);
+        g = m.row_gs[srow] + off;
+        if (!ovf) {
+          const float4 me = A[m.row_lds[srow] + off];
+          const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
+          const float ninv = -c.inv_hh;
+          const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+          // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
+          auto sweep_run = [&](int ri, int rr) {
             const int rb = m.row_lds[rr];
             int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
             const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-            if (je - j > 32) mvalid = 0u;  // more candidates than mask bits: this particle sweeps everything
+            if (je - j <= 32) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
             unsigned int mask = 0u;
             for (; j < je; j += 4) {
 #pragma unroll
@@ -316,22 +366,38 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
               }
             }
             nmask[(size_t)ri * mstride + g] = mask;
+          };
+          if (ts.k == 1) {  // the common full pass keeps the plain 3x3 nest
+            int ri = 0;
+#pragma unroll 1
+            for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+              for (int dy = -1; dy <= 1; ++dy, ++ri) sweep_run(ri, srow + dz + dy);
+            }
+          } else {
+#pragma unroll 1
+            for (int ri = ts.sub; ri < 9; ri += ts.k) sweep_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
           }
+          acc += acc1;
+        } else if (ts.sub == 0) {
+          const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
+          for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+            if (j == g) return;
+            const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+            const float r2 = dist2<true>(dx, dy, dz);
+            if (r2 < c.hh) {
+              const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+              acc = __builtin_fmaf(c.mass * c.A, q * q, acc);
+            }
+          });
         }
-        acc = (acc + acc1) - 1.0f;  // the particle met itself once (q = 1)
-        acc = acc * (c.mass * c.A);
-      } else {
-        const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
-        for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
-          if (j == g) return;
-          const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
-          const float r2 = dist2<true>(dx, dy, dz);
-          if (r2 < c.hh) {
-            const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
-            acc = __builtin_fmaf(c.mass * c.A, q * q, acc);
-          }
-        });
       }
+      for (int o = 1; o < ts.k; o <<= 1) {  // block-uniform trip count
+        acc += __shfl_xor(acc, o, kWave);
+        mvalid |= __shfl_xor(mvalid, o, kWave);
+      }
+      if (!ts.active || ts.sub != 0) continue;
+      if (!ovf) acc = (acc - 1.0f) * (c.mass * c.A);  // the particle met itself once (q = 1)
       rho[g] = acc;
       nmask[(size_t)9 * mstride + g] = mvalid;
       // An isolated particle (rho = 0) has no neighbour for which the reference would ever form
@@ -354,9 +420,12 @@ constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
 
 // WANT_XS adds the build-defined XSPH and cohesion sums (BASELINE configs[4]) to the same sweep;
 // with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
-template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false>
-__global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
+// SLAB compiles in the multi-GPU logic (ownership, ghost tiles, split step); the single-domain
+// instantiations carry none of it.
+template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false>
+__global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
+    const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
     const unsigned int* __restrict__ nmask, int mstride) {
@@ -365,17 +434,26 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
   __shared__ float4 B[kTCap];  // vx,vy,vz,1/rho
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
   unsigned int vbits = 0u, fbits = 0u;  // max|v|, max|F| of this lane over all its tiles
-  TileWalk walk(*n_tiles);
+  // SLAB: after the tiles with owned cell layers, the ghost-only tiles (second list, walked the same
+  // XCD-chunked way so that their small cost is spread evenly): nothing is staged for those, their
+  // targets are just marked for removal (a particle that float rounding puts on the owned side of
+  // the plane after all takes the global-memory sweep).
+  const int nphase = (SLAB && ghost_tiles != nullptr) ? 2 : 1;
+  for (int phase = 0; phase < nphase; ++phase) {
+  const bool ghost_tile = phase == 1;
+  const int* __restrict__ list = ghost_tile ? ghost_tiles : tiles;
+  TileWalk walk(ghost_tile ? *n_ghost_tiles : *n_tiles);
   int item;
   while (walk.next(item)) {
-    const int tile = tiles[item];
+    const int tile = list[item];
     DSL_STAMP(t0);
     __syncthreads();
     tile_setup(c, tg, tile, cell_start, m);
     DSL_STAMP(t1);
     DSL_STAMP_ADD(0, t0, t1);
     const bool ovf = m.overflow != 0;
-    if (!ovf) {
+    const bool nolds = ovf || ghost_tile;  // owned targets of such a tile take the global-memory sweep
+    if (!nolds) {
       stage_rows<8>(
           m, wid, lane,
           [&](int g, float* o) {
@@ -426,12 +504,16 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
         vx = vin.x[g];
         vy = vin.y[g];
         vz = vin.z[g];
-        owned = OUT != kOutIntegrate || slab_owned(c, px, py, pz);
+        owned = !SLAB || OUT != kOutIntegrate || slab_owned(c, px, py, pz);
+        if constexpr (SLAB && OUT == kOutIntegrate) {
+          // split slab step: this launch integrates the band cell layers or the others, not both
+          if (owned && c.split_part != 0 && slab_band_cell(c, slab_axis_cell(c, px, py, pz)) != (c.split_part == 1)) continue;
+        }
       }
       if (owned) {
         float gx = 0.f, gy = 0.f, gz = 0.f, lx_ = 0.f, ly_ = 0.f, lz_ = 0.f;
         float cohx = 0.f, cohy = 0.f, cohz = 0.f;  // cohesion sum
-        if (!ovf) {
+        if (!nolds) {
           if constexpr (WANT_G || WANT_V || WANT_XS) {
             const float pti = WANT_G ? pterm[g] : 0.f;
             const float ninvh = -c.inv_h;
@@ -478,7 +560,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                 xw_ += wx;
               }
             };
-            const bool masked = nmask != nullptr && nmask[(size_t)9 * mstride + g] != 0u;
+            const unsigned int runs_masked = nmask != nullptr ? nmask[(size_t)9 * mstride + g] : 0u;
             DSL_STAMP(t4);
             DSL_STAMP_ADD(2, t3, t4);
             int ri = 0;
@@ -490,25 +572,28 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
                 const int rb = m.row_lds[rr];
                 int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
                 const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-                if (masked) {
-                  // walk the in-range bits of this run; bit (K-1-k) <-> candidate k of the run,
-                  // K = run length rounded up to the density sweep's unroll of 4
-                  unsigned int mm = nmask[(size_t)ri * mstride + g];
+                // Walk the in-range bits of this run; bit (K-1-k) <-> candidate k of the run, K = run
+                // length rounded up to the density sweep's unroll of 4.  A run without a mask (more
+                // than 32 candidates, or no masks at all) is walked in chunks of 32 with every bit set.
+                const bool has_mask = (runs_masked >> ri) & 1u;
+                do {
+                  const int clen = min(je - j, 32);
+                  unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
+                  int top = j + clen - 1;
+                  if (has_mask) {
+                    mm = nmask[(size_t)ri * mstride + g];
+                    top = j + ((clen + 3) & ~3) - 1;
+                  }
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: measures the per-tile fixed cost (set-up + staging + epilogue)
                   mm = 0u;
 #endif
-                  const int top = j + (((je - j) + 3) & ~3) - 1;
                   while (mm) {
                     const int b = __builtin_ctz(mm);
                     mm &= mm - 1u;
                     pair(top - b);
                   }
-                } else {
-                  for (; j < je; j += 2) {
-                    pair(j);
-                    pair(j + 1);
-                  }
-                }
+                  j += 32;
+                } while (j < je);
               }
             }
             DSL_STAMP(t5);
@@ -613,6 +698,12 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
       float npx = px, npy = py, npz = pz, nvx = vx, nvy = vy, nvz = vz;
       integrate_core(c, fx, fy, fz, npx, npy, npz, nvx, nvy, nvz, vbits, fbits, xsx, xsy, xsz);
       if (owned) {
+        // split slab step: an interior-tile particle must not end up inside a band that has
+        // already been packed (chk_* are -inf/+inf unless this is the interior launch)
+        if constexpr (SLAB) {
+          const float pa = c.slab_axis == 0 ? npx : (c.slab_axis == 1 ? npy : npz);
+          if (pa < c.chk_lo || pa >= c.chk_hi) stats->band_missed = 1;
+        }
         pout.x[g] = npx;
         pout.y[g] = npy;
         pout.z[g] = npz;
@@ -630,6 +721,7 @@ __global__ __launch_bounds__(kTBlock) void k_force_integrate_tiled(
       }
     }
   }
+  }  // phase
   if constexpr (OUT == kOutIntegrate) {
     wave_atomic_max(&stats->max_vel_bits, vbits);
     wave_atomic_max(&stats->max_f_bits, fbits);

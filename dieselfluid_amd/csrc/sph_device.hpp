@@ -39,6 +39,10 @@ struct DevConsts {
   // slab ownership (multi-GPU): axis < 0 = everything owned
   int slab_axis;
   float slab_lo, slab_hi;
+  float chk_lo, chk_hi;  // split slab step: integrated coordinates must stay in [chk_lo, chk_hi)
+  int split_cl, split_ch;  // split slab step: band cell layers are < split_cl or >= split_ch
+  int split_part;          // 0 = integrate everything, 1 = band cell layers only, 2 = the others only
+  int own_c0, own_c1;      // cell layers [own_c0, own_c1) along the slab axis can hold owned particles
   // slab mode keeps the live particle count on the device (no host sync per step);
   // nullptr = use n
   const int* n_ptr;
@@ -55,7 +59,7 @@ struct DevStats {
   int pci_iters;
   int pci_done;
   int max_cell_count;
-  int pad;
+  int band_missed;  // split slab step: an interior particle moved further than the split margin
 };
 
 // ---------------------------------------------------------------------------------
@@ -138,6 +142,18 @@ __device__ __forceinline__ bool slab_owned(const DevConsts& c, float x, float y,
   if (c.slab_axis < 0) return true;
   const float p = c.slab_axis == 0 ? x : (c.slab_axis == 1 ? y : z);
   return p >= c.slab_lo && p < c.slab_hi;  // false for NaN
+}
+
+// Split slab step: the force pass first integrates the particles of the BAND cell layers --
+// cell index < split_cl or >= split_ch along the slab axis: everything within width + margin of
+// a slab plane -- then, while that band is packed and sent, the particles of the other layers.
+// The same rule, on a particle's cell before the step, tells the band pack which slots the first
+// launch has integrated.
+constexpr int kTB = 4;  // tile edge in cells (kernels_tiled.hpp)
+__device__ __forceinline__ bool slab_band_cell(const DevConsts& c, int ca) { return ca < c.split_cl || ca >= c.split_ch; }
+__device__ __forceinline__ int slab_axis_cell(const DevConsts& c, float x, float y, float z) {
+  const int a = c.slab_axis;
+  return cell_coord(a == 0 ? x : (a == 1 ? y : z), c.gmin[a], c.inv_cell, c.dims[a]);
 }
 
 // Where neighbour candidates come from: the uniform grid (cell_start) or the reference's

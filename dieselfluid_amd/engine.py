@@ -138,12 +138,34 @@ class SPHEngine:
     def slab_config(self, axis: int, lo: float, hi: float):
         self._ck(self._L.dsl_slab_config(self._h, int(axis), C.c_float(lo), C.c_float(hi)))
 
-    def slab_pack(self, width: float, dev_lo: int, dev_hi: int, capacity: int):
-        self._ck(self._L.dsl_slab_pack(self._h, C.c_float(width), C.c_void_p(dev_lo or None),
-                                       C.c_void_p(dev_hi or None), int(capacity)))
+    def slab_message_floats(self, cap_full: int, cap_xonly: int) -> int:
+        return int(self._L.dsl_slab_message_floats(int(cap_full), int(cap_xonly)))
 
-    def slab_append(self, dev_msg: int, capacity: int):
-        self._ck(self._L.dsl_slab_append(self._h, C.c_void_p(dev_msg), int(capacity)))
+    def slab_split(self, width: float, margin: float):
+        self._ck(self._L.dsl_slab_split(self._h, C.c_float(width), C.c_float(margin)))
+
+    def slab_pack(self, width_full: float, width: float, dev_lo: int, dev_hi: int, cap_full: int, cap_xonly: int):
+        self._ck(self._L.dsl_slab_pack(self._h, C.c_float(width_full), C.c_float(width), C.c_void_p(dev_lo or None),
+                                       C.c_void_p(dev_hi or None), int(cap_full), int(cap_xonly)))
+
+    def slab_pack_band(self, width_full: float, dev_lo: int, dev_hi: int, cap_full: int, cap_xonly: int,
+                       stream: int = 0):
+        """between force_pass_split(BAND) and (INNER): packs the integrated band on `stream`"""
+        self._ck(self._L.dsl_slab_pack_band(self._h, C.c_float(width_full), C.c_void_p(dev_lo or None),
+                                            C.c_void_p(dev_hi or None), int(cap_full), int(cap_xonly),
+                                            C.c_void_p(stream or None)))
+
+    def force_pass_split(self, phase: int):
+        self._ck(self._L.dsl_force_pass_split(self._h, int(phase)))
+
+    def slab_append(self, dev_msg: int, cap_full: int, cap_xonly: int):
+        self._ck(self._L.dsl_slab_append(self._h, C.c_void_p(dev_msg), int(cap_full), int(cap_xonly)))
+
+    def slab_status(self, reset_high_water: bool = False):
+        """(overflow, band_missed, high-water full, high-water position-only); blocking"""
+        st = (C.c_int32 * 4)()
+        self._ck(self._L.dsl_slab_status(self._h, st, 1 if reset_high_water else 0))
+        return tuple(int(v) for v in st)
 
     def slab_overflow(self) -> int:
         v = C.c_int(0)

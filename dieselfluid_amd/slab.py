@@ -26,39 +26,78 @@ import torch.distributed as dist
 from . import scenes
 from .engine import SPHEngine
 
-RECORD = 7  # x,y,z,vx,vy,vz,id-bits
+RECORD = 7    # full record: x,y,z,vx,vy,vz,id-bits
+RECORD_X = 3  # position-only record
+SPLIT_BAND, SPLIT_INNER = 1, 2
 
 
-def message_count(msg: torch.Tensor) -> int:
-    """record count stored (as int32 bits) in the header record of a message"""
-    return int(msg[0, :1].cpu().contiguous().view(torch.int32).item())
+def message_floats(cap_full: int, cap_x: int) -> int:
+    """header record + full records + position-only records (include/dslsph.h)"""
+    return (cap_full + 1) * RECORD + cap_x * RECORD_X
+
+
+def message_counts(msg: torch.Tensor):
+    """(full, position-only) record counts stored as int32 bits in the header"""
+    hdr = msg[:2].cpu().contiguous().view(torch.int32)
+    return int(hdr[0]), int(hdr[1])
 
 
 class HipSlabEngine:
-    """SPHEngine + device message buffers (torch tensors used as plain device memory).
-    A message is (capacity+1) x 7 floats: header record (count) + records."""
+    """SPHEngine + device message buffers (torch tensors used as plain device memory)."""
 
-    def __init__(self, params, device: int, band_capacity: int):
+    def __init__(self, params, device: int, cap_full: int, cap_x: int, max_scale: float = 2.0):
         self.eng = SPHEngine(params, device=device)
         self.dev = torch.device("cuda", device)
-        self.band_capacity = int(band_capacity)
-        self._send = [torch.zeros((self.band_capacity + 1, RECORD), dtype=torch.float32, device=self.dev)
+        self.max_full, self.max_x = int(max_scale * cap_full), int(max_scale * cap_x)
+        self.cap_full, self.cap_x = int(cap_full), int(cap_x)
+        self._send = [torch.zeros(message_floats(self.max_full, self.max_x), dtype=torch.float32, device=self.dev)
                       for _ in range(2)]
         # kernels and NCCL ops are ordered through torch's current stream
         self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.supports_split = params.math_mode == 1
+        self.comm_stream = torch.cuda.Stream(self.dev) if self.supports_split else None
+
+    def set_caps(self, cap_full: int, cap_x: int):
+        self.cap_full, self.cap_x = min(int(cap_full), self.max_full), min(int(cap_x), self.max_x)
+
+    def message_floats(self) -> int:
+        return message_floats(self.cap_full, self.cap_x)
+
+    def _views(self, want_lo, want_hi):
+        n = self.message_floats()
+        return (self._send[0][:n] if want_lo else None, self._send[1][:n] if want_hi else None)
 
     # -- protocol -------------------------------------------------------------------
-    def pack(self, width: float, want_lo: bool, want_hi: bool):
+    def pack(self, width_full: float, width: float, want_lo: bool, want_hi: bool):
         """Asynchronous: both band messages are filled on the device, counts included."""
-        self.eng.slab_pack(width, self._send[0].data_ptr() if want_lo else 0,
-                           self._send[1].data_ptr() if want_hi else 0, self.band_capacity)
-        return (self._send[0] if want_lo else None, self._send[1] if want_hi else None)
+        self.eng.slab_pack(width_full, width, self._send[0].data_ptr() if want_lo else 0,
+                           self._send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x)
+        return self._views(want_lo, want_hi)
+
+    def split(self, width: float, margin: float):
+        self.eng.slab_split(width, margin)
+
+    def force_band(self):
+        self.eng.force_pass_split(SPLIT_BAND)
+
+    def pack_band(self, width_full: float, want_lo: bool, want_hi: bool):
+        """on comm_stream, which the library makes wait for the band phase only"""
+        self.eng.slab_pack_band(width_full, self._send[0].data_ptr() if want_lo else 0,
+                                self._send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x,
+                                self.comm_stream.cuda_stream)
+        return self._views(want_lo, want_hi)
+
+    def force_inner(self):
+        self.eng.force_pass_split(SPLIT_INNER)
 
     def append(self, msg: torch.Tensor):
         m = msg if msg.device == self.dev else msg.to(self.dev)
         # the engine runs on torch's current stream, so the caching allocator's stream-ordered
         # reuse keeps m's memory valid until the append kernel has run
-        self.eng.slab_append(m.contiguous().data_ptr(), self.band_capacity)
+        self.eng.slab_append(m.contiguous().data_ptr(), self.cap_full, self.cap_x)
+
+    def status(self, reset_high_water: bool = False):
+        return self.eng.slab_status(reset_high_water)
 
     def nn(self):
         self.eng.nn()
@@ -70,13 +109,14 @@ class HipSlabEngine:
         self.eng.force_pass()
 
     def owned_state(self, axis, lo, hi):
-        """Particles this rank is responsible for between steps: after a step the ghosts
-        carry NaN positions, so everything finite is owned or has just crossed a plane
-        (and will be handed over at the next exchange)."""
+        """Particles this rank is responsible for: finite positions inside [lo,hi).  After a
+        step the old ghosts carry NaN, the freshly received ones and the particles that have
+        just left (already handed over by the end-of-step exchange) lie outside [lo,hi)."""
         ids = self.eng.download_ids()
         pos = self.eng.download("positions", sorted_order=True)
         vel = self.eng.download("velocities", sorted_order=True)
-        own = np.isfinite(pos).all(axis=1)
+        with np.errstate(invalid="ignore"):
+            own = np.isfinite(pos).all(axis=1) & (pos[:, axis] >= np.float32(lo)) & (pos[:, axis] < np.float32(hi))
         return ids[own], pos[own], vel[own]
 
     @property
@@ -85,53 +125,101 @@ class HipSlabEngine:
 
 
 class SlabDriver:
-    """Runs the WCSPH step on one slab and exchanges the 2h band with the two neighbours."""
+    """Runs the WCSPH step on one slab and exchanges the 2h band with the two neighbours.
 
-    def __init__(self, engine, rank: int, world: int, axis: int, planes, width: float, group=None):
+    The exchange for step t+1 happens at the END of step t.  With an engine that supports the
+    split force pass it is started as soon as the tiles near the planes are integrated and
+    runs (pack, RCCL send/recv) on a side stream while the interior tiles are integrated."""
+
+    REPLAN_EVERY = 8  # steps between message-size re-plans (one host sync + one tiny all-reduce)
+
+    def __init__(self, engine, rank: int, world: int, axis: int, planes, width: float, width_full: float,
+                 group=None, overlap=None, margin: float = 0.0):
         assert len(planes) == world + 1
-        self.engine, self.rank, self.world, self.axis, self.width, self.group = engine, rank, world, axis, width, group
+        self.engine, self.rank, self.world, self.axis, self.group = engine, rank, world, axis, group
+        self.width, self.width_full = width, width_full
         self.lo = -math.inf if rank == 0 else float(planes[rank])
         self.hi = math.inf if rank == world - 1 else float(planes[rank + 1])
         self.backend = dist.get_backend(group) if world > 1 else "none"
         self.comm_dev = torch.device("cpu") if self.backend != "nccl" else getattr(engine, "dev", torch.device("cuda"))
+        self.overlap = bool(getattr(engine, "supports_split", False) and world > 1) if overlap is None else overlap
+        self.margin = margin
         self.steps = 0
         self._recv = None
+        self._ghosts_in = False  # the ghosts for the next step are already appended
 
     # -- halo + migration exchange ----------------------------------------------------
     def _neighbours(self):
         return (self.rank - 1 if self.rank > 0 else None, self.rank + 1 if self.rank < self.world - 1 else None)
 
-    def exchange(self):
-        """One fixed-size message per neighbour and direction; the record count travels in the
-        message header, so nothing here waits for the GPU (with NCCL, Work.wait() only orders
-        the current stream behind the transfer)."""
-        if self.world == 1:
-            return
-        lo_nb, hi_nb = self._neighbours()
-        send = self.engine.pack(self.width, lo_nb is not None, hi_nb is not None)
-        nbs = [lo_nb, hi_nb]
-        if self._recv is None:
-            cap = self.engine.band_capacity
-            self._recv = [torch.zeros((cap + 1, RECORD), dtype=torch.float32, device=self.comm_dev) for _ in range(2)]
+    def _post(self, send):
+        """starts the transfer of one fixed-size message per neighbour and direction; the record
+        counts travel in the message headers, so nothing here waits for the GPU"""
+        nbs = self._neighbours()
+        n = self.engine.message_floats()
+        if self._recv is None or self._recv[0].numel() < n:
+            full = message_floats(getattr(self.engine, "max_full", self.engine.cap_full),
+                                  getattr(self.engine, "max_x", self.engine.cap_x))
+            self._recv = [torch.zeros(max(full, n), dtype=torch.float32, device=self.comm_dev) for _ in range(2)]
         sbuf = [None if s is None else (s if s.device == self.comm_dev else s.to(self.comm_dev)) for s in send]
         ops = []
         for k in range(2):
             if nbs[k] is not None:
                 ops.append(dist.P2POp(dist.isend, sbuf[k], nbs[k], group=self.group))
-                ops.append(dist.P2POp(dist.irecv, self._recv[k], nbs[k], group=self.group))
-        for w in dist.batch_isend_irecv(ops):
+                ops.append(dist.P2POp(dist.irecv, self._recv[k][:n], nbs[k], group=self.group))
+        return (dist.batch_isend_irecv(ops) if ops else []), n, sbuf
+
+    def _finish(self, posted):
+        """with NCCL, Work.wait() only orders the current stream behind the transfer"""
+        works, n, _keep = posted
+        for w in works:
             w.wait()
+        nbs = self._neighbours()
         for k in range(2):
             if nbs[k] is not None:
-                self.engine.append(self._recv[k])
+                self.engine.append(self._recv[k][:n])
+        self._ghosts_in = True
+
+    def exchange(self):
+        if self.world == 1:
+            return
+        lo_nb, hi_nb = self._neighbours()
+        send = self.engine.pack(self.width_full, self.width, lo_nb is not None, hi_nb is not None)
+        self._finish(self._post(send))
+
+    def _replan(self):
+        """message sizes follow the band occupancy: every rank learns the largest counts seen
+        anywhere since the last re-plan and all switch to the same new capacities"""
+        st = self.engine.status(reset_high_water=True)
+        hw = torch.tensor([st[2], st[3]], dtype=torch.int64, device=self.comm_dev)
+        dist.all_reduce(hw, op=dist.ReduceOp.MAX, group=self.group)
+        hw_full, hw_x = (int(v) for v in hw.cpu())
+        self.engine.set_caps(int(1.15 * hw_full) + 1024, int(1.15 * hw_x) + 1024)
 
     def wcsph_step(self, nsteps: int = 1):
+        e = self.engine
+        lo_nb, hi_nb = self._neighbours()
         for _ in range(nsteps):
-            self.exchange()             # migrants + 2h ghosts from both neighbours
-            self.engine.nn()            # counting sort; drops the previous step's ghosts
-            self.engine.density_all()   # owned + ghosts
-            self.engine.force_pass()    # owned only; ghosts are marked for removal
+            if not self._ghosts_in:
+                self.exchange()      # first step: migrants + 2h ghosts from both neighbours
+            e.nn()                   # counting sort; drops the previous step's ghosts
+            e.density_all()          # owned + ghosts
+            self._ghosts_in = False
+            if self.world == 1:
+                e.force_pass()
+            elif self.overlap:
+                e.force_band()       # owned particles of the tiles near the planes
+                with torch.cuda.stream(e.comm_stream):
+                    send = e.pack_band(self.width_full, lo_nb is not None, hi_nb is not None)
+                    posted = self._post(send)
+                e.force_inner()      # the rest, concurrently with the transfer
+                self._finish(posted)
+            else:
+                e.force_pass()       # owned only; ghosts are marked for removal
+                self.exchange()
             self.steps += 1
+            if self.world > 1 and self.steps % self.REPLAN_EVERY == 0:
+                self._replan()
 
     # -- validation helper ---------------------------------------------------------------
     def gather_state(self, n_total: int):
@@ -155,7 +243,7 @@ class SlabDriver:
     # -- the bench / test scene ---------------------------------------------------------------
     @classmethod
     def dambreak(cls, n3: int, math_mode: int = 1, device: int = 0, axis: int = 2, rank=None, world=None,
-                 engine_factory=None, group=None, vel_fn=None, **scene_kw):
+                 engine_factory=None, group=None, vel_fn=None, overlap=None, tile_align=True, **scene_kw):
         """Dam-break of n3^3 particles split into `world` slabs along `axis` (default z: the
         collapse is symmetric in z, so the slabs stay balanced without re-planning)."""
         rank = dist.get_rank(group) if rank is None else rank
@@ -165,31 +253,50 @@ class SlabDriver:
         dx = L / n3
         h = p.h
         width = 2.0 * h
-        # split the n3 lattice layers along the axis evenly; planes sit between layers
+        # Split the n3 lattice layers along the axis; planes sit between layers.  Slab thicknesses
+        # are multiples of 4 grid cells (8 layers at h = 2dx) where that costs little balance, so
+        # that both planes of a rank fall on the planes of its 4-cell tiles (see below).
+        per = max(1, round(4.0 * h / dx))
         layer = [round(r * n3 / world) for r in range(world + 1)]
+        if tile_align and n3 >= 2 * per * world:
+            layer = [min(n3, per * round(r * n3 / (world * per))) for r in range(world)] + [n3]
         planes = [l * dx for l in layer]
         k0, k1 = layer[rank], layer[rank + 1]
         ids = scenes.dambreak_slab_ids(n3, axis, k0, k1)
         pos = scenes.dambreak_positions_ids(n3, dx, ids, scene_kw.get("jitter", 0.05), scene_kw.get("seed", 1234))
         n_local = ids.shape[0]
-        band = int(1.5 * n3 * n3 * math.ceil(width / dx)) + 1024
+        width_full = h
+        cap_full = int(1.25 * n3 * n3 * math.ceil(width_full / dx)) + 1024
+        cap_x = int(1.25 * n3 * n3 * math.ceil((width - width_full) / dx)) + 1024
+        max_scale = 2.0
         p.n_particles = n_local
-        p.capacity = int(1.25 * n_local) + 2 * band + 1024
-        # the neighbour grid only has to cover this slab plus its ghost band
+        p.capacity = int(1.25 * n_local) + int(2 * max_scale * (cap_full + cap_x)) + 1024
+        # The neighbour grid only has to cover this slab plus its ghost band.  It starts a whole
+        # number of 4-cell tiles below the lower plane (two empty cell layers, then the two ghost
+        # layers), so tile planes coincide with the slab planes: the force pass stages no tile that
+        # is half ghosts, and the band layers of the split step (the cells within width + margin =
+        # 4 cells of a plane, include/dslsph.h) are whole tile layers.
+        margin = 2.0 * h
         if world > 1:
-            gmin = (planes[rank] - width - h) if rank > 0 else p.grid_min[axis]
-            gmax = (planes[rank + 1] + width + h) if rank < world - 1 else p.grid_max[axis]
-            p.grid_min[axis] = max(gmin, p.grid_min[axis])
+            tile = 4.0 * h
+            if rank > 0:
+                gmin = planes[rank] - tile
+            else:  # first rank: align with its upper plane instead
+                gmin = planes[1] - tile * math.ceil((planes[1] - p.grid_min[axis]) / tile - 1e-6)
+            gmax = (planes[rank + 1] + width) if rank < world - 1 else p.grid_max[axis]
+            p.grid_min[axis] = gmin
             p.grid_max[axis] = min(gmax, p.grid_max[axis])
-        engine = (engine_factory or HipSlabEngine)(p, device, band)
+        engine = (engine_factory or HipSlabEngine)(p, device, cap_full, cap_x)
         eng = engine.eng if hasattr(engine, "eng") else engine
         eng.upload("positions", pos)
         if vel_fn is not None:
             eng.upload("velocities", np.ascontiguousarray(vel_fn(ids, pos), dtype=np.float32))
         eng.set_ids(ids)
         eng.reset_forces()
-        drv = cls(engine, rank, world, axis, planes, width, group=group)
+        drv = cls(engine, rank, world, axis, planes, width, width_full, group=group, overlap=overlap, margin=margin)
         eng.slab_config(axis, drv.lo, drv.hi)
+        if drv.overlap:
+            engine.split(width, margin)
         drv.params = p
         drv.n_total = n3 ** 3
         return drv

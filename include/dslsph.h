@@ -234,32 +234,59 @@ int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
 /* ---- multi-GPU: spatial slabs, one process per GPU -----------------------------------
  * The reference has no multi-process path; these entry points are
  * what a host needs to run one slab per GPU and exchange a halo with its two neighbours
- * (over RCCL, by whatever transport the host owns).  A record is 7 floats:
- * x,y,z,vx,vy,vz and the global particle id as raw int32 bits.
+ * (over RCCL, by whatever transport the host owns).
  *
- * A message is a DEVICE buffer of (capacity+1) records: record 0 is a header whose first word
- * is the record count (int32 bits), records 1..count follow.  Messages have a fixed size, so
- * a step needs no host-side counts and no host synchronisation: the live particle count
- * stays on the device.
+ * A message is a DEVICE buffer of dsl_slab_message_floats(cap_full, cap_xonly) floats:
+ *   header  : 7 words; [0] = number of full records, [1] = number of position-only records
+ *             (int32 bits)
+ *   full    : cap_full records of 7 floats: x,y,z,vx,vy,vz and the global particle id as
+ *             raw int32 bits -- every owned particle within width_full of the plane, and the
+ *             migrants beyond it
+ *   x-only  : cap_xonly records of 3 floats: x,y,z -- the rest of the band (out to `width`);
+ *             they only feed the receiver's ghost densities
+ * Messages have a fixed size, so a step needs no host-side counts and no host
+ * synchronisation: the live particle count stays on the device.  With width_full = h and
+ * width = 2h the receiver recomputes the ghosts' densities itself and the force pass needs
+ * no second exchange.
  *
  * dsl_slab_config : this handle owns [lo,hi) along `axis` (use -INFINITY / INFINITY at the
  *                   domain ends); particles outside are ghosts: they take part in the
  *                   neighbour sums but are not integrated and are dropped at the next
  *                   neighbour build.
- * dsl_slab_pack   : writes every owned particle with pos[axis] < lo+width into dev_lo and
- *                   every one with pos[axis] >= hi-width into dev_hi (migrants included);
- *                   either pointer may be NULL.  Asynchronous.
+ * dsl_slab_pack   : packs the bands of both sides (either pointer may be NULL) from the
+ *                   current state.  Asynchronous.
  * dsl_slab_append : appends the records of a received message behind the current
- *                   particles; they are owned if inside [lo,hi), ghosts otherwise.
+ *                   particles; full records are owned if inside [lo,hi), ghosts otherwise.
  *                   Asynchronous.
- * dsl_slab_overflow: largest count that did not fit a message or the particle capacity
- *                   since creation (0 = none); blocking, for diagnostics.
+ * dsl_slab_status : [0] largest count that did not fit a message or the particle capacity
+ *                   since creation (0 = none), [1] 1 if the split step's margin was ever
+ *                   exceeded, [2],[3] largest full / position-only band counts since the last
+ *                   reset; blocking.  dsl_slab_overflow returns [0] only.
  * After appending, dsl_build_neighbours drops the previous step's ghosts (the integrate
  * kernels mark them with NaN positions).  A particle that has just crossed the plane stays
- * one more step as a ghost of its old owner. */
+ * one more step as a ghost of its old owner.
+ *
+ * Split step (hides the exchange behind the interior force pass; DSL_MATH_FAST only):
+ *   dsl_slab_split(h, width, margin) once; then per step, after the density pass,
+ *   dsl_force_pass_split(h, DSL_SPLIT_BAND)   force+integrate for the particles of the grid-cell
+ *                                             layers that reach within width+margin of a plane,
+ *   dsl_slab_pack_band(h, ..., stream)        packs the integrated band on `stream` (which is
+ *                                             made to wait for the band phase only),
+ *   dsl_force_pass_split(h, DSL_SPLIT_INNER)  the remaining layers, concurrently with the
+ *                                             transfer the host started on `stream`.
+ *   `margin` must exceed the distance a particle can move in one step (dsl_slab_status[1]
+ *   reports a violation). */
+enum { DSL_SPLIT_BAND = 1, DSL_SPLIT_INNER = 2 };
+size_t dsl_slab_message_floats(int cap_full, int cap_xonly);
 int dsl_slab_config(dsl_handle *h, int axis, float lo, float hi);
-int dsl_slab_pack(dsl_handle *h, float width, float *dev_lo, float *dev_hi, int capacity);
-int dsl_slab_append(dsl_handle *h, const float *dev_message, int capacity);
+int dsl_slab_split(dsl_handle *h, float width, float margin);
+int dsl_slab_pack(dsl_handle *h, float width_full, float width, float *dev_lo, float *dev_hi, int cap_full,
+                  int cap_xonly);
+int dsl_slab_pack_band(dsl_handle *h, float width_full, float *dev_lo, float *dev_hi, int cap_full, int cap_xonly,
+                       void *stream);
+int dsl_force_pass_split(dsl_handle *h, int phase);
+int dsl_slab_append(dsl_handle *h, const float *dev_message, int cap_full, int cap_xonly);
+int dsl_slab_status(dsl_handle *h, int32_t status[4], int reset_high_water);
 int dsl_slab_overflow(dsl_handle *h, int *high_water);
 int dsl_get_count(dsl_handle *h, int *n_live, int *n_owned); /* blocking */
 /* global particle ids of the current slots (host order of dsl_upload); default 0..n-1 */

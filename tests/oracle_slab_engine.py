@@ -8,21 +8,37 @@ import torch
 import helpers
 from oracle import pyoracle as po
 
-RECORD = 7
+RECORD, RECORD_X = 7, 3
 
 
 class OracleSlabEngine:
-    def __init__(self, params, device, band_capacity):
+    supports_split = False
+
+    def __init__(self, params, device, cap_full, cap_x):
         self.p = params
         self.q = helpers.oracle_params(params)
         self.capacity = params.capacity or params.n_particles
-        self.band_capacity = band_capacity
+        self.cap_full, self.cap_x = int(cap_full), int(cap_x)
+        self.max_full, self.max_x = 2 * self.cap_full, 2 * self.cap_x
+        self.hw = [0, 0]
         self.pos = np.zeros((0, 3), np.float32)
         self.vel = np.zeros((0, 3), np.float32)
         self.ids = np.zeros((0,), np.int32)
         self.axis, self.lo, self.hi = -1, -np.inf, np.inf
         self.keep_from = 0
         self._sys = None
+
+    def set_caps(self, cap_full, cap_x):
+        self.cap_full, self.cap_x = min(int(cap_full), self.max_full), min(int(cap_x), self.max_x)
+
+    def message_floats(self):
+        return (self.cap_full + 1) * RECORD + self.cap_x * RECORD_X
+
+    def status(self, reset_high_water=False):
+        st = (0, 0, self.hw[0], self.hw[1])
+        if reset_high_water:
+            self.hw = [0, 0]
+        return st
 
     # -- set-up (mirrors SPHEngine) -------------------------------------------------
     def upload(self, name, arr):
@@ -52,34 +68,41 @@ class OracleSlabEngine:
             return (pos[:, self.axis] >= self.lo) & (pos[:, self.axis] < self.hi)
 
     # -- protocol ---------------------------------------------------------------------
-    def _message(self, take):
-        """(capacity+1) x 7 message: header record holds the count as int32 bits"""
-        n = int(take.sum())
-        assert n <= self.band_capacity
-        msg = np.zeros((self.band_capacity + 1, RECORD), np.float32)
-        msg[0, 0] = np.array([n], np.int32).view(np.float32)[0]
-        msg[1:n + 1, 0:3], msg[1:n + 1, 3:6] = self.pos[take], self.vel[take]
-        msg[1:n + 1, 6] = self.ids[take].view(np.float32)
+    def _message(self, full, xonly):
+        """header (counts as int32 bits) + cap_full full records + cap_x position-only records"""
+        nf, nx = int(full.sum()), int(xonly.sum())
+        assert nf <= self.cap_full and nx <= self.cap_x
+        self.hw = [max(self.hw[0], nf), max(self.hw[1], nx)]
+        msg = np.zeros(self.message_floats(), np.float32)
+        msg[0:2] = np.array([nf, nx], np.int32).view(np.float32)
+        rec = msg[RECORD:RECORD * (1 + self.cap_full)].reshape(-1, RECORD)
+        rec[:nf, 0:3], rec[:nf, 3:6] = self.pos[full], self.vel[full]
+        rec[:nf, 6] = self.ids[full].view(np.float32)
+        msg[RECORD * (1 + self.cap_full):].reshape(-1, RECORD_X)[:nx] = self.pos[xonly]
         return torch.from_numpy(msg)
 
-    def pack(self, width, want_lo, want_hi):
+    def pack(self, width_full, width, want_lo, want_hi):
         a = self.pos[:, self.axis]
         finite = np.isfinite(self.pos).all(axis=1)
         with np.errstate(invalid="ignore"):
-            lo = finite & (a < np.float32(self.lo + width))
-            hi = finite & (a >= np.float32(self.hi - width))
-        return (self._message(lo) if want_lo else None, self._message(hi) if want_hi else None)
+            lo_f = finite & (a < np.float32(self.lo + width_full))
+            lo_x = finite & ~lo_f & (a < np.float32(self.lo + width))
+            hi_f = finite & (a >= np.float32(self.hi - width_full))
+            hi_x = finite & ~hi_f & (a >= np.float32(self.hi - width))
+        return (self._message(lo_f, lo_x) if want_lo else None, self._message(hi_f, hi_x) if want_hi else None)
 
     def append(self, msg):
         m = msg.cpu().numpy()
-        n = int(m[0, :1].view(np.int32)[0])
-        if n == 0:
+        nf, nx = (int(v) for v in m[0:2].view(np.int32))
+        if nf + nx == 0:
             return
-        r = m[1:n + 1]
-        assert self.pos.shape[0] + n <= self.capacity
-        self.pos = np.concatenate([self.pos, r[:, 0:3]])
-        self.vel = np.concatenate([self.vel, r[:, 3:6]])
-        self.ids = np.concatenate([self.ids, np.ascontiguousarray(r[:, 6]).view(np.int32)])
+        assert self.pos.shape[0] + nf + nx <= self.capacity
+        r = m[RECORD:RECORD * (1 + self.cap_full)].reshape(-1, RECORD)[:nf]
+        x = m[RECORD * (1 + self.cap_full):].reshape(-1, RECORD_X)[:nx]
+        self.pos = np.concatenate([self.pos, r[:, 0:3], x])
+        self.vel = np.concatenate([self.vel, r[:, 3:6], np.zeros_like(x)])
+        self.ids = np.concatenate([self.ids, np.ascontiguousarray(r[:, 6]).view(np.int32),
+                                   np.full(nx, -1, np.int32)])
 
     def nn(self):
         # stale ghosts carry NaN; a particle that just crossed the plane stays one more
@@ -101,7 +124,10 @@ class OracleSlabEngine:
         self._sys = None
 
     def owned_state(self, axis, lo, hi):
-        own = np.isfinite(self.pos).all(axis=1)  # ghosts carry NaN after a step
+        # old ghosts carry NaN after a step; fresh ghosts and departed particles lie outside [lo,hi)
+        with np.errstate(invalid="ignore"):
+            own = np.isfinite(self.pos).all(axis=1) & (self.pos[:, axis] >= np.float32(lo)) & \
+                (self.pos[:, axis] < np.float32(hi))
         return self.ids[own], self.pos[own], self.vel[own]
 
     @property

@@ -1,0 +1,95 @@
+"""One-GPU estimate of a MIDDLE slab rank's step cost (tools only, not part of the product).
+
+The rank's two neighbours are emulated by periodic images of the rank itself: the band it
+packs for the lower neighbour comes back, shifted by the slab thickness, as the ghosts of the
+upper neighbour and vice versa.  Everything a real middle rank does per step (pack, append,
+ghost sort, ghost densities, split force pass) runs unchanged; only the RCCL transfer is
+replaced by a device copy on the same stream.  Usage:
+  python tools/slab_periodic_bench.py [--n3 252] [--world 8] [--steps 50] [--no-overlap]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import torch.distributed as dist
+
+from dieselfluid_amd import slab
+
+
+class PeriodicDriver(slab.SlabDriver):
+    def _shift(self, msg, dz):
+        e = self.engine
+        out = msg.clone()
+        full = out[slab.RECORD:slab.RECORD * (1 + e.cap_full)].view(-1, slab.RECORD)
+        xo = out[slab.RECORD * (1 + e.cap_full):slab.message_floats(e.cap_full, e.cap_x)].view(-1, slab.RECORD_X)
+        full[:, self.axis] += dz
+        xo[:, self.axis] += dz
+        return out
+
+    def _post(self, send):
+        T = self.hi - self.lo
+        # my lo band is what the (image) upper neighbour receives from below, and vice versa
+        self._images = [self._shift(send[1], -T), self._shift(send[0], +T)]
+        return None
+
+    def _finish(self, posted):
+        if self.overlap:  # the main stream waits for the side stream's pack + copies
+            torch.cuda.current_stream().wait_stream(self.engine.comm_stream)
+        for m in self._images:
+            self.engine.append(m)
+        self._ghosts_in = True
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n3", type=int, default=252)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-exchange", action="store_true", help="same slab and grid, no ghosts at all")
+    ap.add_argument("--no-timing", action="store_true")
+    ap.add_argument("--null-stream", action="store_true", help="run on torch's default (null) stream")
+    a = ap.parse_args()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    if not a.null_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
+    drv = PeriodicDriver.dambreak(a.n3, math_mode=1, device=0, rank=a.rank, world=a.world,
+                                  overlap=not a.no_overlap)
+    drv.comm_dev = torch.device("cpu")
+    if a.no_exchange:
+        drv.world = 1
+    eng = drv.engine_core
+    drv.wcsph_step(a.warmup)
+    eng.timing_reset()
+    eng.timing_enable(not a.no_timing)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.wcsph_step(a.steps)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.timing_enable(False)
+    st = drv.engine.status()
+    stats = eng.stats()
+    n_live, n_owned = eng.n, eng.n_owned()
+    out = {"ms_per_step": round(dt / a.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "owned": n_owned, "live_with_ghosts": n_live,
+           "overlap": drv.overlap, "max_cell_count": stats.max_cell_count, "grid": list(stats.grid_dims), "status": st, "caps": [drv.engine.cap_full, drv.engine.cap_x],
+           "message_MB": round(drv.engine.message_floats() * 4 / 1e6, 3),
+           "kernels_ms_per_step": {k: round(eng.timing(k)[0] * eng.timing(k)[1] / a.steps, 4) for k in
+                                   ("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")},
+           "ideal_ms_at_1gpu_rate": None}
+    print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
