@@ -57,6 +57,11 @@ struct dsl_handle {
   int *bucket_of = nullptr, *lsh_table = nullptr, *lsh_len = nullptr, *lsh_samples = nullptr;
   TileGrid tg{};
   int *tiles = nullptr, *n_tiles = nullptr;
+  // tile statistics read back without ever waiting for them: [0] non-empty tiles, [5] tiles with a
+  // short last pass -> which instantiation of the tiled kernels the next launches use
+  int* host_tstats = nullptr;
+  hipEvent_t ev_tstats = nullptr;
+  bool tstats_pending = false, share_short = false;
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -367,9 +372,14 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     HIP_TRY(h, hipMemsetAsync(h->n_tiles, 0, 8 * sizeof(int), h->stream));
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
-                         h->cell_start, h->tiles, h->n_tiles);
+                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5);
     });
     if (rc) return rc;
+    if (h->host_tstats && !h->tstats_pending) {
+      HIP_TRY(h, hipMemcpyAsync(h->host_tstats, h->n_tiles, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(h, hipEventRecord(h->ev_tstats, h->stream));
+      h->tstats_pending = true;
+    }
   }
   if (h->c.n_ptr) {
     // stale ghosts were sorted into the extra bucket `ncell`; the live count stays on the device
@@ -403,13 +413,28 @@ int persistent_grid(const dsl_handle* h, int blocks_per_cu) {
   return g < 8 ? 8 : g;
 }
 
+// Short passes (kernels_tiled.hpp: for_each_target) are shared out by a second copy of the sweep
+// that costs a few per cent where every tile holds exactly one full pass (a lattice at rest).
+// Which instantiation runs follows the tile statistics of the latest neighbour build whose
+// read-back has arrived; it is never waited for.
+void poll_tile_stats(dsl_handle* h) {
+  if (!h->tstats_pending || hipEventQuery(h->ev_tstats) != hipSuccess) return;
+  h->tstats_pending = false;
+  h->share_short = (long long)h->host_tstats[5] * 12 > (long long)h->host_tstats[0];
+}
+
 int density_pass(dsl_handle* h) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
   if (h->prm.math_mode == DSL_MATH_FAST) {
+    poll_tile_stats(h);
     int rc = timed(h, DSL_K_DENSITY, [&] {
-      hipLaunchKernelGGL(k_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles,
-                         h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap);
+      if (h->share_short)
+        hipLaunchKernelGGL(k_density_tiled<true>, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap);
+      else
+        hipLaunchKernelGGL(k_density_tiled<false>, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap);
     });
     if (rc) return rc;
     h->dens_fresh = true;
@@ -452,12 +477,18 @@ int force_integrate(dsl_handle* h, int part = 0) {
   const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
   int rc = DSL_OK;
   if (use_tiled(h)) {
+    poll_tile_stats(h);
     rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
       dim3 g(persistent_grid(h, 2)), b(kTBlock);
-#define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                                                           \
-  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS>), g, b, 0, h->stream, c, h->tg,   \
-                     tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo,  \
-                     h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap)
+#define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
+  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
+                     h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
+                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap)
+#define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                        \
+  do {                                                                        \
+    if (XX || h->share_short) DSL_LAUNCH_FT4(GG, VV, XX, SS, true);           \
+    else DSL_LAUNCH_FT4(GG, VV, false, SS, false);                            \
+  } while (0)
 #define DSL_LAUNCH_FT2(GG, VV, XX)                     \
   do {                                                \
     if (c.slab_axis >= 0) DSL_LAUNCH_FT3(GG, VV, XX, true); \
@@ -473,6 +504,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
       else if (G) DSL_LAUNCH_FT(true, false);
       else if (V) DSL_LAUNCH_FT(false, true);
       else DSL_LAUNCH_FT(false, false);
+#undef DSL_LAUNCH_FT4
 #undef DSL_LAUNCH_FT3
 #undef DSL_LAUNCH_FT2
 #undef DSL_LAUNCH_FT
@@ -624,6 +656,8 @@ void free_all(dsl_handle* h) {
       (void)hipEventDestroy(pr.second);
     }
   if (h->ev_band) (void)hipEventDestroy(h->ev_band);
+  if (h->ev_tstats) (void)hipEventDestroy(h->ev_tstats);
+  if (h->host_tstats) (void)hipHostFree(h->host_tstats);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -759,6 +793,13 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
   if (h->prm.math_mode == DSL_MATH_FAST && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
+  if (h->prm.math_mode == DSL_MATH_FAST) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_tstats), 8 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tstats, hipEventDisableTiming) != hipSuccess) {
+      h->err = "tile statistics buffer";
+      return bail(DSL_ERR_DEVICE);
+    }
+  }
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
   for (int k = 0; k < 6 && me == hipSuccess; ++k) me = hipMemsetAsync(h->pv[0][k], 0, n * sizeof(float), h->stream);

@@ -69,7 +69,8 @@ __device__ unsigned long long g_diag[8];
 // contain band cell layers and [2] those that contain other layers (a tile straddling the
 // limit is in both).
 __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
-                                                      int* __restrict__ tiles, int* __restrict__ n_tiles) {
+                                                      int* __restrict__ tiles, int* __restrict__ n_tiles,
+                                                      int* __restrict__ short_pass_tiles) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   int cnt = 0;
@@ -91,6 +92,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
       in_band = owning && (a0 < c.split_cl || a1 > c.split_ch);
       in_inner = owning && max(a0, c.split_cl) < min(a1, c.split_ch);
     }
+  }
+  // tiles whose last pass is short (more than kTBlock targets, or at most half of it): the host
+  // picks the kernel instantiation that shares such passes out from this count
+  {
+    const unsigned long long sp = __ballot(cnt > kTBlock || (cnt > 0 && cnt <= kTBlock / 2));
+    if (sp != 0ull && lane == 0) atomicAdd(short_pass_tiles, __builtin_popcountll(sp));
   }
   // one atomic per wave and list (same-address atomics serialise)
 #pragma unroll
@@ -260,21 +267,30 @@ __device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane,
   }
 }
 
-// How the next pass over a tile's targets is shared out (see k_density_tiled): with `rem` targets
-// left, k = 1, 2, 4 or 8 adjacent lanes work on each target; `count` targets are taken.
-struct TargetSplit {
-  int k, sub, target, count;
-  bool active;
-  __device__ __forceinline__ TargetSplit(int rem, int tid, int tperm) {
-    const int shift = rem > kTBlock / 2 ? 0 : (rem > kTBlock / 4 ? 1 : (rem > kTBlock / 8 ? 2 : 3));
-    k = 1 << shift;
-    const int idx = shift == 0 ? tperm : tid;  // the bank-conflict permutation only pays for full passes
-    target = idx >> shift;
-    sub = idx & (k - 1);
-    count = min(rem, kTBlock >> shift);
-    active = target < count;
+// Passes over a tile's targets (see k_density_tiled).  Full passes: one lane per target,
+// body(false_type, t, 0, 1), lanes permuted for conflict-free ds_read_b128.  When at most half a
+// block of targets is left, k = 2, 4 or 8 adjacent lanes share each target:
+// body(true_type, t, sub, k) with sub = 0..k-1; the lanes of a group run the body together, so it
+// may combine their sums with __shfl_xor over offsets 1..k/2.
+// SHARE = false compiles the full passes only (every pass one lane per target): the instantiation
+// for a scene whose tiles hold exactly kTBlock targets (a lattice at rest) is a few per cent faster
+// without the second copy of the body; the host picks per step from the tile statistics.
+template <bool SHARE, class Body>
+__device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, Body&& body) {
+  int tbase = 0;
+  for (; SHARE ? ntarg - tbase > kTBlock / 2 : tbase < ntarg; tbase += kTBlock) {
+    const int t = tbase + tperm;
+    if (t < ntarg) body(std::false_type{}, t, 0, 1);
   }
-};
+  if constexpr (SHARE)
+  while (tbase < ntarg) {
+    const int rem = ntarg - tbase;
+    const int shift = rem > kTBlock / 4 ? 1 : (rem > kTBlock / 8 ? 2 : 3);
+    const int t = tid >> shift;
+    if (t < rem) body(std::true_type{}, tbase + t, tid & ((1 << shift) - 1), 1 << shift);
+    tbase += min(rem, kTBlock >> shift);
+  }
+}
 
 // ---------------------------------------------------------------------------------
 // D (tiled): densities + P/rho^2
@@ -286,6 +302,7 @@ struct TargetSplit {
 // expanded form at ~2e-6 h^2 -- inside the FAST-mode tolerance, and invisible to the cut-off
 // (a candidate that far out contributes ~1e-12).
 // ---------------------------------------------------------------------------------
+template <bool SHARE>
 __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
                                                           const int* __restrict__ n_tiles,
                                                           const int* __restrict__ cell_start, CSoa3 p,
@@ -329,74 +346,71 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     // Targets are taken kTBlock at a time, one lane each.  A tile's LDS slot is held for as long as
     // its slowest pass, so a short pass -- the few targets beyond kTBlock once the lattice has
     // melted, or a half-empty tile at a slab end -- is shared out: 2, 4 or 8 adjacent lanes per
-    // target, each sweeping every k-th of the 9 runs, sums combined by shuffles.
-    for (int tbase = 0; tbase < ntarg;) {
-      const TargetSplit ts(ntarg - tbase, tid, tperm);
-      const int t = tbase + ts.target;
-      tbase += ts.count;
-      int g = 0;
+    // target, each sweeping every k-th of the 9 runs, sums combined by shuffles (for_each_target).
+    for_each_target<SHARE>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
+      constexpr bool SHARED = decltype(shared_c)::value;
+      int srow, off;
+      tile_target(m, t, srow, off);
+      const int g = m.row_gs[srow] + off;
       float acc = 0.0f, acc1 = 0.0f;
       unsigned int mvalid = 0u;
-      if (ts.active) {
-        int srow, off;
-        tile_target(m, t, srow, off);
-        g = m.row_gs[srow] + off;
-        if (!ovf) {
-          const float4 me = A[m.row_lds[srow] + off];
-          const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
-          const float ninv = -c.inv_hh;
-          const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
-          // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
-          auto sweep_run = [&](int ri, int rr) {
-            const int rb = m.row_lds[rr];
-            int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-            const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-            if (je - j <= 32) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
-            unsigned int mask = 0u;
-            for (; j < je; j += 4) {
+      if (!ovf) {
+        const float4 me = A[m.row_lds[srow] + off];
+        const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
+        const float ninv = -c.inv_hh;
+        const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+        // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
+        auto sweep_run = [&](int ri, int rr) {
+          const int rb = m.row_lds[rr];
+          int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
+          const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+          if (je - j <= 32) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
+          unsigned int mask = 0u;
+          for (; j < je; j += 4) {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float4 cnd = A[j + u];
-                // r^2 = |xi|^2 + |xj|^2 - 2 xi.xj ; q = clamp(1 - r^2/h^2)
-                const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
-                const float q = fma_clamp01(r2, ninv, 1.0f);
-                mask_push(mask, q);
-                if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
-                else acc = __builtin_fmaf(q, q, acc);
-              }
+            for (int u = 0; u < 4; ++u) {
+              const float4 cnd = A[j + u];
+              // r^2 = |xi|^2 + |xj|^2 - 2 xi.xj ; q = clamp(1 - r^2/h^2)
+              const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
+              const float q = fma_clamp01(r2, ninv, 1.0f);
+              mask_push(mask, q);
+              if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+              else acc = __builtin_fmaf(q, q, acc);
             }
-            nmask[(size_t)ri * mstride + g] = mask;
-          };
-          if (ts.k == 1) {  // the common full pass keeps the plain 3x3 nest
-            int ri = 0;
-#pragma unroll 1
-            for (int dz = -kTH; dz <= kTH; dz += kTH) {
-#pragma unroll 1
-              for (int dy = -1; dy <= 1; ++dy, ++ri) sweep_run(ri, srow + dz + dy);
-            }
-          } else {
-#pragma unroll 1
-            for (int ri = ts.sub; ri < 9; ri += ts.k) sweep_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
           }
-          acc += acc1;
-        } else if (ts.sub == 0) {
-          const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
-          for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
-            if (j == g) return;
-            const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
-            const float r2 = dist2<true>(dx, dy, dz);
-            if (r2 < c.hh) {
-              const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
-              acc = __builtin_fmaf(c.mass * c.A, q * q, acc);
-            }
-          });
+          nmask[(size_t)ri * mstride + g] = mask;
+        };
+        if constexpr (!SHARED) {
+          int ri = 0;
+#pragma unroll 1
+          for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+            for (int dy = -1; dy <= 1; ++dy, ++ri) sweep_run(ri, srow + dz + dy);
+          }
+        } else {
+#pragma unroll 1
+          for (int ri = sub; ri < 9; ri += k) sweep_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
         }
+        acc += acc1;
+      } else if (sub == 0) {
+        const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
+        for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+          if (j == g) return;
+          const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+          const float r2 = dist2<true>(dx, dy, dz);
+          if (r2 < c.hh) {
+            const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+            acc = __builtin_fmaf(c.mass * c.A, q * q, acc);
+          }
+        });
       }
-      for (int o = 1; o < ts.k; o <<= 1) {  // block-uniform trip count
-        acc += __shfl_xor(acc, o, kWave);
-        mvalid |= __shfl_xor(mvalid, o, kWave);
+      if constexpr (SHARED) {
+        for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
+          acc += __shfl_xor(acc, o, kWave);
+          mvalid |= __shfl_xor(mvalid, o, kWave);
+        }
+        if (sub != 0) return;
       }
-      if (!ts.active || ts.sub != 0) continue;
       if (!ovf) acc = (acc - 1.0f) * (c.mass * c.A);  // the particle met itself once (q = 1)
       rho[g] = acc;
       nmask[(size_t)9 * mstride + g] = mvalid;
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       // visit the particle itself, so its own term has to be a harmless 0 rather than 0/0.
       const float pr = tait_eos<true>(c, acc, c.eos_d0_grad);
       pterm[g] = acc > 0.0f ? dsl_div<true>(pr, acc * acc) : 0.0f;
-    }
+    });
   }
 }
 
@@ -422,8 +436,10 @@ constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
 // with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
 // SLAB compiles in the multi-GPU logic (ownership, ghost tiles, split step); the single-domain
 // instantiations carry none of it.
-template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false>
-__global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void k_force_integrate_tiled(
+template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false, bool SHARE = true>
+// (Two 8-wave workgroups per CU need <= 128 VGPRs.  The headline instantiation gets there on its
+// own and schedules best unconstrained; the others are held to 4 waves/SIMD.)
+__global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
     const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
@@ -486,7 +502,10 @@ __global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void
     const int ntarg = m.tprefix[kTB * kTB];
     const int x0 = (tile % tg.tnx) * kTB - 1;
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
-    for (int t = tperm; t < ntarg; t += kTBlock) {
+    // short passes are shared out as in k_density_tiled: k lanes per target, each walking every
+    // k-th run; after the butterfly the group's first lane finishes the target
+    for_each_target<SHARE>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
+      constexpr bool SHARED = decltype(shared_c)::value;
       const bool live = true;
       DSL_STAMP(t3);
       int srow = kTH + 1, off = 0, g = 0;
@@ -507,7 +526,7 @@ __global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void
         owned = !SLAB || OUT != kOutIntegrate || slab_owned(c, px, py, pz);
         if constexpr (SLAB && OUT == kOutIntegrate) {
           // split slab step: this launch integrates the band cell layers or the others, not both
-          if (owned && c.split_part != 0 && slab_band_cell(c, slab_axis_cell(c, px, py, pz)) != (c.split_part == 1)) continue;
+          if (owned && c.split_part != 0 && slab_band_cell(c, slab_axis_cell(c, px, py, pz)) != (c.split_part == 1)) return;
         }
       }
       if (owned) {
@@ -563,41 +582,70 @@ __global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void
             const unsigned int runs_masked = nmask != nullptr ? nmask[(size_t)9 * mstride + g] : 0u;
             DSL_STAMP(t4);
             DSL_STAMP_ADD(2, t3, t4);
-            int ri = 0;
-#pragma unroll 1
-            for (int dz = -kTH; dz <= kTH; dz += kTH) {
-#pragma unroll 1
-              for (int dy = -1; dy <= 1; ++dy, ++ri) {
-                const int rr = srow + dz + dy;
-                const int rb = m.row_lds[rr];
-                int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-                const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-                // Walk the in-range bits of this run; bit (K-1-k) <-> candidate k of the run, K = run
-                // length rounded up to the density sweep's unroll of 4.  A run without a mask (more
-                // than 32 candidates, or no masks at all) is walked in chunks of 32 with every bit set.
-                const bool has_mask = (runs_masked >> ri) & 1u;
-                do {
-                  const int clen = min(je - j, 32);
-                  unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
-                  int top = j + clen - 1;
-                  if (has_mask) {
-                    mm = nmask[(size_t)ri * mstride + g];
-                    top = j + ((clen + 3) & ~3) - 1;
-                  }
+            // Walk the in-range bits of one run (row rr of the staged tile, the 3 cells around the
+            // target's); bit (K-1-k) <-> candidate k of the run, K = run length rounded up to the
+            // density sweep's unroll of 4.  A run without a mask (more than 32 candidates, or no masks
+            // at all) is walked in chunks of 32 with every bit set.
+            auto walk_run = [&](int ri, int rr) {
+              const int rb = m.row_lds[rr];
+              int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
+              const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+              const bool has_mask = (runs_masked >> ri) & 1u;
+              do {
+                const int clen = min(je - j, 32);
+                unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
+                int top = j + clen - 1;
+                if (has_mask) {
+                  mm = nmask[(size_t)ri * mstride + g];
+                  top = j + ((clen + 3) & ~3) - 1;
+                }
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: measures the per-tile fixed cost (set-up + staging + epilogue)
-                  mm = 0u;
+                mm = 0u;
 #endif
-                  while (mm) {
-                    const int b = __builtin_ctz(mm);
-                    mm &= mm - 1u;
-                    pair(top - b);
-                  }
-                  j += 32;
-                } while (j < je);
+                while (mm) {
+                  const int b = __builtin_ctz(mm);
+                  mm &= mm - 1u;
+                  pair(top - b);
+                }
+                j += 32;
+              } while (j < je);
+            };
+            if constexpr (!SHARED) {
+              int ri = 0;
+#pragma unroll 1
+              for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+                for (int dy = -1; dy <= 1; ++dy, ++ri) walk_run(ri, srow + dz + dy);
               }
+            } else {
+#pragma unroll 1
+              for (int ri = sub; ri < 9; ri += k) walk_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
             }
             DSL_STAMP(t5);
             DSL_STAMP_ADD(3, t4, t5);
+            if constexpr (SHARED)
+            for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
+              if constexpr (WANT_G) {
+                gx += __shfl_xor(gx, o, kWave);
+                gy += __shfl_xor(gy, o, kWave);
+                gz += __shfl_xor(gz, o, kWave);
+              }
+              if constexpr (WANT_V) {
+                lx_ += __shfl_xor(lx_, o, kWave);
+                ly_ += __shfl_xor(ly_, o, kWave);
+                lz_ += __shfl_xor(lz_, o, kWave);
+                lw_ += __shfl_xor(lw_, o, kWave);
+              }
+              if constexpr (WANT_XS) {
+                cohx += __shfl_xor(cohx, o, kWave);
+                cohy += __shfl_xor(cohy, o, kWave);
+                cohz += __shfl_xor(cohz, o, kWave);
+                xsx += __shfl_xor(xsx, o, kWave);
+                xsy += __shfl_xor(xsy, o, kWave);
+                xsz += __shfl_xor(xsz, o, kWave);
+                xw_ += __shfl_xor(xw_, o, kWave);
+              }
+            }
             if constexpr (WANT_V) {
               lx_ = __builtin_fmaf(-vx, lw_, lx_);
               ly_ = __builtin_fmaf(-vy, lw_, ly_);
@@ -678,6 +726,9 @@ __global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void
       } else {
         vx = vy = vz = 0.f;  // not integrated: keep ghosts and idle lanes out of the counters
       }
+      if constexpr (SHARED) {
+        if (sub != 0) return;  // the group's first lane finishes the target
+      }
       if constexpr (OUT == kOutAddForce) {
         pout.x[g] += fx;
         pout.y[g] += fy;
@@ -687,13 +738,13 @@ __global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void
           vout.y[g] = xsy;
           vout.z[g] = xsz;
         }
-        continue;
+        return;
       }
       if constexpr (OUT == kOutStore) {
         pout.x[g] = fx;
         pout.y[g] = fy;
         pout.z[g] = fz;
-        continue;
+        return;
       }
       float npx = px, npy = py, npz = pz, nvx = vx, nvy = vy, nvz = vz;
       integrate_core(c, fx, fy, fz, npx, npy, npz, nvx, nvy, nvz, vbits, fbits, xsx, xsy, xsz);
@@ -719,7 +770,7 @@ __global__ __launch_bounds__(kTBlock) __attribute__((amdgpu_num_vgpr(128))) void
         vout.y[g] = vin.y[g];
         vout.z[g] = vin.z[g];
       }
-    }
+    });
   }
   }  // phase
   if constexpr (OUT == kOutIntegrate) {

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace dsl {
 
 constexpr int kWave = 64;

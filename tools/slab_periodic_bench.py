@@ -31,12 +31,35 @@ class PeriodicDriver(slab.SlabDriver):
         return out
 
     def _post(self, send):
+        if self.use_nccl:
+            return self._post_nccl(send)
         T = self.hi - self.lo
         # my lo band is what the (image) upper neighbour receives from below, and vice versa
         self._images = [self._shift(send[1], -T), self._shift(send[0], +T)]
         return None
 
+    def _post_nccl(self, send):
+        """real RCCL point-to-point calls, addressed to this very rank: the same batch_isend_irecv /
+        Work.wait() / stream ordering as the multi-GPU driver, minus the wire"""
+        n = self.engine.message_floats()
+        if self._recv is None:
+            full = slab.message_floats(self.engine.max_full, self.engine.max_x)
+            self._recv = [torch.zeros(full, dtype=torch.float32, device=self.engine.dev) for _ in range(2)]
+        ops = [dist.P2POp(dist.isend, send[1], 0), dist.P2POp(dist.irecv, self._recv[0][:n], 0),
+               dist.P2POp(dist.isend, send[0], 0), dist.P2POp(dist.irecv, self._recv[1][:n], 0)]
+        return dist.batch_isend_irecv(ops), n
+
     def _finish(self, posted):
+        if self.use_nccl:
+            works, n = posted
+            for w in works:
+                w.wait()
+            T = self.hi - self.lo
+            self._images = [self._shift(self._recv[0][:n], -T), self._shift(self._recv[1][:n], +T)]
+            for m in self._images:
+                self.engine.append(m)
+            self._ghosts_in = True
+            return
         if self.overlap:  # the main stream waits for the side stream's pack + copies
             torch.cuda.current_stream().wait_stream(self.engine.comm_stream)
         for m in self._images:
@@ -55,16 +78,24 @@ def main():
     ap.add_argument("--no-exchange", action="store_true", help="same slab and grid, no ghosts at all")
     ap.add_argument("--no-timing", action="store_true")
     ap.add_argument("--null-stream", action="store_true", help="run on torch's default (null) stream")
+    ap.add_argument("--no-replan", action="store_true", help="no message re-sizing (and so no host sync) in the timed loop")
+    ap.add_argument("--nccl", action="store_true", help="send the bands through RCCL (to this same rank)")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
-    dist.init_process_group("gloo", rank=0, world_size=1)
     torch.cuda.set_device(0)
+    if a.nccl:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
     if not a.null_stream:
         torch.cuda.set_stream(torch.cuda.Stream())
     drv = PeriodicDriver.dambreak(a.n3, math_mode=1, device=0, rank=a.rank, world=a.world,
                                   overlap=not a.no_overlap)
-    drv.comm_dev = torch.device("cpu")
+    drv.comm_dev = torch.device("cuda", 0) if a.nccl else torch.device("cpu")
+    drv.use_nccl = a.nccl
+    if a.no_replan:
+        PeriodicDriver.REPLAN_EVERY = 10 ** 9
     if a.no_exchange:
         drv.world = 1
     eng = drv.engine_core
