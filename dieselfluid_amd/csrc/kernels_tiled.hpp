@@ -15,7 +15,8 @@
 // knows which (q > 0) and emits one 32-bit mask per x-run (9 words per particle, bit order =
 // visit order); the force sweeps then walk only the set bits with the full per-pair
 // arithmetic.  Masks stay valid while positions and slot order do (same step); runs longer
-// than 32 candidates clear their bit in the particle's "valid" word and are swept in full.
+// than 32 candidates get a second word, runs longer than 64 clear their bit in the particle's
+// "valid" word and are swept in full.
 //
 // Work distribution: k_tile_list compacts the non-empty tiles (the dam-break box is ~8x
 // larger than the fluid); a persistent grid walks that list, contiguous chunks per XCD so
@@ -35,7 +36,11 @@ constexpr int kTPad = 4;               // pad records per staged row (over-read 
 constexpr int kTCap = 2304;            // staged records per tile (1.33 x the 1728 of 8 per cell)
 constexpr float kFar = 1.0e15f;        // pad coordinate: finite, far outside any domain
 constexpr int kTileLists = 5;
-constexpr int kMaskWords = 10;         // 9 run masks + 1 valid word per particle (SoA, stride = capacity)
+// per particle (SoA, stride = capacity): words 0-8 the masks of the 9 runs (first 32 candidates),
+// word 9 the valid bits, words 10-18 the masks of candidates 32-63 (written and read only for runs
+// that long)
+constexpr int kMaskWords = 19;
+constexpr int kMaskValid = 9, kMaskHigh = 10;
 
 struct TileMeta {
   int row_gs[kTRows];        // first global slot of the staged row
@@ -269,7 +274,7 @@ __device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane,
 
 // Passes over a tile's targets (see k_density_tiled).  Full passes: one lane per target,
 // body(false_type, t, 0, 1), lanes permuted for conflict-free ds_read_b128.  When at most half a
-// block of targets is left, k = 2, 4 or 8 adjacent lanes share each target:
+// block of targets is left, k = 2, 4, 8 or 16 adjacent lanes share each target:
 // body(true_type, t, sub, k) with sub = 0..k-1; the lanes of a group run the body together, so it
 // may combine their sums with __shfl_xor over offsets 1..k/2.
 // SHARE = false compiles the full passes only (every pass one lane per target): the instantiation
@@ -285,7 +290,7 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
   if constexpr (SHARE)
   while (tbase < ntarg) {
     const int rem = ntarg - tbase;
-    const int shift = rem > kTBlock / 4 ? 1 : (rem > kTBlock / 8 ? 2 : 3);
+    const int shift = rem > kTBlock / 4 ? 1 : (rem > kTBlock / 8 ? 2 : (rem > kTBlock / 16 ? 3 : 4));  // 16: one run per lane
     const int t = tid >> shift;
     if (t < rem) body(std::true_type{}, tbase + t, tid & ((1 << shift) - 1), 1 << shift);
     tbase += min(rem, kTBlock >> shift);
@@ -295,11 +300,12 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
 // ---------------------------------------------------------------------------------
 // D (tiled): densities + P/rho^2
 //
-// Candidate coordinates are staged RELATIVE TO THE TILE CENTRE together with their squared
-// norm w = |x|^2, so that r^2 = |xi|^2 + w_j - 2 xi.xj costs one add and three fma instead of
-// three subtractions and three fma (the kernel is bound by FP32 issue, profiles/r01_v3_pmc.md).
+// Candidate coordinates are staged RELATIVE TO THE TILE CENTRE together with w = -|x|^2/h^2, so
+// that q = 1 - r^2/h^2 = (1 + w_i) + w_j + (2/h^2) xi.xj costs one add and three fma, the last
+// with the clamp modifier (7 VALU instructions per candidate with the mask push and the
+// accumulation; the kernel is bound by FP32 issue, profiles/r01_v3_pmc.md).
 // Tile-relative values stay below 3.5 cells, which bounds the cancellation error of the
-// expanded form at ~2e-6 h^2 -- inside the FAST-mode tolerance, and invisible to the cut-off
+// expanded form at ~2e-6 -- inside the FAST-mode tolerance, and invisible to the cut-off
 // (a candidate that far out contributes ~1e-12).
 // ---------------------------------------------------------------------------------
 template <bool SHARE>
@@ -331,10 +337,10 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
             o[2] = p.z[g];
           },
           [&](int slot, const float* o, bool real) {
-            float4 v = make_float4(kFar, kFar, kFar, 3.0f * kFar * kFar);
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
             if (real) {
               const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
-              v = make_float4(x, y, z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
             }
             A[slot] = v;
           });
@@ -356,29 +362,38 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       unsigned int mvalid = 0u;
       if (!ovf) {
         const float4 me = A[m.row_lds[srow] + off];
-        const float m2x = -2.0f * me.x, m2y = -2.0f * me.y, m2z = -2.0f * me.z, ni = me.w;
-        const float ninv = -c.inv_hh;
+        const float two_hh = 2.0f * c.inv_hh;
+        const float sx = two_hh * me.x, sy = two_hh * me.y, sz = two_hh * me.z, a0 = 1.0f + me.w;
         const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
         // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
         auto sweep_run = [&](int ri, int rr) {
           const int rb = m.row_lds[rr];
           int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
           const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-          if (je - j <= 32) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
+          if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
           unsigned int mask = 0u;
-          for (; j < je; j += 4) {
+          auto sweep_to = [&](int jend) {
+            for (; j < jend; j += 4) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const float4 cnd = A[j + u];
-              // r^2 = |xi|^2 + |xj|^2 - 2 xi.xj ; q = clamp(1 - r^2/h^2)
-              const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
-              const float q = fma_clamp01(r2, ninv, 1.0f);
-              mask_push(mask, q);
-              if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
-              else acc = __builtin_fmaf(q, q, acc);
+              for (int u = 0; u < 4; ++u) {
+                const float4 cnd = A[j + u];
+                // q = clamp(1 - r^2/h^2), r^2 = |xi|^2 + |xj|^2 - 2 xi.xj, with everything but the
+                // three products folded into the staged w_j = -|xj|^2/h^2 and the per-target constants
+                const float q = fma_clamp01(cnd.z, sz, __builtin_fmaf(cnd.y, sy, __builtin_fmaf(cnd.x, sx, cnd.w + a0)));
+                mask_push(mask, q);
+                if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+                else acc = __builtin_fmaf(q, q, acc);
+              }
             }
-          }
+          };
+          const int j32 = j + 32;
+          sweep_to(min(je, j32));
           nmask[(size_t)ri * mstride + g] = mask;
+          if (je > j32) {  // a second word for candidates 32-63 (rare: occupancy 8.3 +- 2 per cell once melted);
+            mask = 0u;     // a run longer than 64 leaves garbage in it, its valid bit is clear
+            sweep_to(je);
+            nmask[(size_t)(kMaskHigh + ri) * mstride + g] = mask;
+          }
         };
         if constexpr (!SHARED) {
           int ri = 0;
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       }
       if (!ovf) acc = (acc - 1.0f) * (c.mass * c.A);  // the particle met itself once (q = 1)
       rho[g] = acc;
-      nmask[(size_t)9 * mstride + g] = mvalid;
+      nmask[(size_t)kMaskValid * mstride + g] = mvalid;
       // An isolated particle (rho = 0) has no neighbour for which the reference would ever form
       // P/rho^2 (sph_field.go:183-199 only does so inside the j != i loop); the masked sweeps do
       // visit the particle itself, so its own term has to be a harmless 0 rather than 0/0.
@@ -579,7 +594,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 xw_ += wx;
               }
             };
-            const unsigned int runs_masked = nmask != nullptr ? nmask[(size_t)9 * mstride + g] : 0u;
+            const unsigned int runs_masked = nmask != nullptr ? nmask[(size_t)kMaskValid * mstride + g] : 0u;
             DSL_STAMP(t4);
             DSL_STAMP_ADD(2, t3, t4);
             // Walk the in-range bits of one run (row rr of the staged tile, the 3 cells around the
@@ -591,13 +606,15 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
               const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
               const bool has_mask = (runs_masked >> ri) & 1u;
+              int word = ri;
               do {
                 const int clen = min(je - j, 32);
                 unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
                 int top = j + clen - 1;
-                if (has_mask) {
-                  mm = nmask[(size_t)ri * mstride + g];
+                if (has_mask) {  // (then the run has at most 64 candidates: two words)
+                  mm = nmask[(size_t)word * mstride + g];
                   top = j + ((clen + 3) & ~3) - 1;
+                  word = kMaskHigh + ri;
                 }
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: measures the per-tile fixed cost (set-up + staging + epilogue)
                 mm = 0u;
