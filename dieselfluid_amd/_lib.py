@@ -98,6 +98,7 @@ EXPORTS = {
     "dsl_slab_pack_band": (C.c_int, [_vp, C.c_float, _vp, _vp, C.c_int, C.c_int, _vp]),
     "dsl_force_pass_split": (C.c_int, [_vp, C.c_int]),
     "dsl_slab_append": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "dsl_slab_append2": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     "dsl_slab_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
     "dsl_slab_overflow": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dsl_get_count": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

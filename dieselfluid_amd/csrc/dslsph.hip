@@ -19,6 +19,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -305,7 +306,6 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
   HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
-  HIP_TRY(h, hipMemsetAsync(&h->dstats->max_cell_count, 0, sizeof(int), h->stream));
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z, h->cellid,
                        h->rank, h->cell_count);
@@ -313,7 +313,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
     hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan, h->dstats,
+                       h->prm.math_mode == DSL_MATH_FAST ? h->n_tiles : nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
                        h->cell_start, h->dstats);
   });
@@ -369,10 +370,9 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (h->pci_active) h->cur_pci ^= 1;
   h->grid_valid = true;
   if (h->prm.math_mode == DSL_MATH_FAST) {
-    HIP_TRY(h, hipMemsetAsync(h->n_tiles, 0, 8 * sizeof(int), h->stream));
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
-                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5);
+                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr);
     });
     if (rc) return rc;
     if (h->host_tstats && !h->tstats_pending) {
@@ -381,8 +381,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
       h->tstats_pending = true;
     }
   }
-  if (h->c.n_ptr) {
-    // stale ghosts were sorted into the extra bucket `ncell`; the live count stays on the device
+  if (h->c.n_ptr && h->prm.math_mode != DSL_MATH_FAST) {
+    // the sort has dropped the stale ghosts; the live count stays on the device (FAST: k_tile_list did it)
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, h->stream, h->dn, h->cell_start + h->ncell);
     HIP_TRY(h, hipGetLastError());
   }
@@ -421,6 +421,7 @@ void poll_tile_stats(dsl_handle* h) {
   if (!h->tstats_pending || hipEventQuery(h->ev_tstats) != hipSuccess) return;
   h->tstats_pending = false;
   h->share_short = (long long)h->host_tstats[5] * 12 > (long long)h->host_tstats[0];
+  if (const char* e = std::getenv("DSL_SHARE_SHORT")) h->share_short = e[0] == '1';  // measurement override
 }
 
 int density_pass(dsl_handle* h) {
@@ -1494,21 +1495,29 @@ int dsl_force_pass_split(dsl_handle* h, int phase) {
   return fail(h, DSL_ERR_INVALID, "dsl_force_pass_split: bad phase");
 }
 
-int dsl_slab_append(dsl_handle* h, const float* dev_message, int cap_full, int cap_xonly) {
+int dsl_slab_append2(dsl_handle* h, const float* dev_message_a, const float* dev_message_b, int cap_full,
+                     int cap_xonly) {
   CHECK_HANDLE(h);
   if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: no slab configured");
-  if (!dev_message || cap_full < 0 || cap_xonly < 0) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
+  if ((!dev_message_a && !dev_message_b) || cap_full < 0 || cap_xonly < 0)
+    return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
   if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: a split force pass is in flight");
   if (!h->forces_uniform) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: forces must be uniform (dsl_reset_forces)");
   if (cap_full + cap_xonly == 0) return DSL_OK;
   Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
-  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(cap_full + cap_xonly)), dim3(kBlock), 0, h->stream, dev_message,
-                     cap_full, cap_xonly, h->dn, h->cap, p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], h->dn + 5);
-  hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message, cap_full, cap_xonly, h->dn, h->cap);
+  hipLaunchKernelGGL(k_slab_append, dim3(grid_for(cap_full + cap_xonly), 2), dim3(kBlock), 0, h->stream, dev_message_a,
+                     dev_message_b, cap_full, cap_xonly, h->dn, h->cap, p.x, p.y, p.z, v.x, v.y, v.z,
+                     h->ids[h->cur_ids], h->dn + 5);
+  hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message_a, dev_message_b, cap_full, cap_xonly,
+                     h->dn, h->cap);
   HIP_TRY(h, hipGetLastError());
   h->grid_valid = false;
   h->dens_fresh = false;
   return DSL_OK;
+}
+
+int dsl_slab_append(dsl_handle* h, const float* dev_message, int cap_full, int cap_xonly) {
+  return dsl_slab_append2(h, dev_message, nullptr, cap_full, cap_xonly);
 }
 
 int dsl_get_count(dsl_handle* h, int* n_live, int* n_owned) {

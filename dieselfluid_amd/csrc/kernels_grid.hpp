@@ -105,9 +105,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ co
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// phase 2: exclusive scan of the tile sums in place (single block)
-__global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sums, int nb) {
+// phase 2: exclusive scan of the tile sums in place (single block).  Runs between the histogram
+// and everything that follows it, so it also clears the small counters of the later kernels
+// (the fullest-cell statistic of phase 3, the tile-list lengths) instead of two more memsets.
+__global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sums, int nb, DevStats* stats,
+                                                     int* __restrict__ n_tiles) {
   __shared__ int lds[kBlock / kWave];
+  if (threadIdx.x == 0) stats->max_cell_count = 0;
+  if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
   int carry = 0;
   for (int base = 0; base < nb; base += kBlock) {
     const int idx = base + threadIdx.x;
@@ -420,22 +425,29 @@ __device__ __forceinline__ void slab_counts(const float* msg, int cap_full, int 
   nx = nx < 0 ? 0 : (nx > cap_x ? cap_x : nx);
 }
 
-// appends the records of a message behind the current particles: full records first, then
-// the position-only ones (velocity 0, id -1: they are ghosts by construction)
-__global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg, int cap_full, int cap_x,
+// appends the records of up to two messages behind the current particles: per message the full
+// records first, then the position-only ones (velocity 0, id -1: they are ghosts by construction).
+// blockIdx.y selects the message; the second one lands behind the first.
+__global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg0,
+                                                        const float* __restrict__ msg1, int cap_full, int cap_x,
                                                         const int* __restrict__ n_cur, int room,
                                                         float* __restrict__ px, float* __restrict__ py,
                                                         float* __restrict__ pz, float* __restrict__ vx,
                                                         float* __restrict__ vy, float* __restrict__ vz,
                                                         int* __restrict__ ids, int* __restrict__ slab_state) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
-  int nf, nx;
-  slab_counts(msg, cap_full, cap_x, nf, nx);
-  const int at = *n_cur;
-  if (at + nf + nx > room) {  // does not fit: record it, append nothing
-    if (k == 0) atomicMax(&slab_state[0], at + nf + nx);
+  int nf0 = 0, nx0 = 0, nf1 = 0, nx1 = 0;
+  if (msg0) slab_counts(msg0, cap_full, cap_x, nf0, nx0);
+  if (msg1) slab_counts(msg1, cap_full, cap_x, nf1, nx1);
+  const int at0 = *n_cur;
+  if (at0 + nf0 + nx0 + nf1 + nx1 > room) {  // does not fit: record it, append nothing
+    if (k == 0 && blockIdx.y == 0) atomicMax(&slab_state[0], at0 + nf0 + nx0 + nf1 + nx1);
     return;
   }
+  const float* msg = blockIdx.y == 0 ? msg0 : msg1;
+  if (!msg) return;
+  const int nf = blockIdx.y == 0 ? nf0 : nf1, nx = blockIdx.y == 0 ? nx0 : nx1;
+  const int at = blockIdx.y == 0 ? at0 : at0 + nf0 + nx0;
   if (k < nf) {
     const float* r = msg + (size_t)(k + 1) * kRecord;
     const int d = at + k;
@@ -459,11 +471,13 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
     ids[d] = -1;
   }
 }
-__global__ void k_slab_bump(const float* __restrict__ msg, int cap_full, int cap_x, int* __restrict__ n_cur,
-                            int room) {
-  int nf, nx;
-  slab_counts(msg, cap_full, cap_x, nf, nx);
-  if (*n_cur + nf + nx <= room) *n_cur += nf + nx;
+__global__ void k_slab_bump(const float* __restrict__ msg0, const float* __restrict__ msg1, int cap_full, int cap_x,
+                            int* __restrict__ n_cur, int room) {
+  int nf0 = 0, nx0 = 0, nf1 = 0, nx1 = 0;
+  if (msg0) slab_counts(msg0, cap_full, cap_x, nf0, nx0);
+  if (msg1) slab_counts(msg1, cap_full, cap_x, nf1, nx1);
+  const int add = nf0 + nx0 + nf1 + nx1;
+  if (*n_cur + add <= room) *n_cur += add;
 }
 __global__ void k_set_count(int* __restrict__ n_cur, const int* __restrict__ src) { *n_cur = *src; }
 

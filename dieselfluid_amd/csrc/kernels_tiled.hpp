@@ -75,8 +75,11 @@ __device__ unsigned long long g_diag[8];
 // limit is in both).
 __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                       int* __restrict__ tiles, int* __restrict__ n_tiles,
-                                                      int* __restrict__ short_pass_tiles) {
+                                                      int* __restrict__ short_pass_tiles, int* __restrict__ n_live) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
+  // slab mode: the sort has dropped the stale ghosts; the live count (kept on the device) is the
+  // start of the pseudo cell behind the last one.  Nothing in this launch reads the count.
+  if (t == 0 && n_live) *n_live = cell_start[c.ncell];
   const int lane = threadIdx.x & (kWave - 1);
   int cnt = 0;
   bool in_band = false, in_inner = false, owning = false, ghosts = false;
@@ -205,22 +208,30 @@ __device__ __forceinline__ int b128_group_slot(int lane) {
 }
 
 // XCD-aware walk of the tile list: blocks b and b+8 share an XCD (and its L2).  The list is dealt
-// to the XCDs in groups of kWalkGroup consecutive tiles (neighbouring tiles share halo rows, so a
+// to the XCDs in groups of up to kWalkGroupMax consecutive tiles (neighbouring tiles share halo rows, so a
 // group mostly hits its XCD's L2), round-robin, so that runs of cheap tiles -- ghost layers,
 // half-empty layers -- do not all land on one XCD.
-constexpr int kWalkGroup = 128;
+constexpr int kWalkGroupMax = 128;
 struct TileWalk {
-  int li, lstep, lend, xcd, n;
+  int li, lstep, xcd, n;  // (kept to four scalars: the kernels that use it are short of SGPRs)
   __device__ __forceinline__ TileWalk(int n_tiles) {
     n = n_tiles;
     xcd = blockIdx.x & 7;
     li = blockIdx.x >> 3;
     lstep = (gridDim.x + 7) >> 3;
-    lend = ((n_tiles + 8 * kWalkGroup - 1) / (8 * kWalkGroup)) * kWalkGroup;  // items an XCD may own
+  }
+  // group size: a power of two, at most kWalkGroupMax, small enough for >= 8 groups per XCD
+  // (a short list dealt in big groups would leave some XCDs a whole group behind)
+  __device__ __forceinline__ int group_shift() const {
+    int s = 3;
+    while ((2 << s) <= kWalkGroupMax && (n >> (s + 1)) >= 64) ++s;
+    return s;
   }
   __device__ __forceinline__ bool next(int& item) {
+    const int gs = group_shift(), g = 1 << gs;
+    const int lend = ((n + 8 * g - 1) / (8 * g)) * g;  // items an XCD may own
     while (li < lend) {
-      item = ((li / kWalkGroup) * 8 + xcd) * kWalkGroup + (li % kWalkGroup);
+      item = ((((li >> gs) << 3) + xcd) << gs) + (li & (g - 1));
       li += lstep;
       if (item < n) return true;
     }

@@ -161,6 +161,10 @@ class SPHEngine:
     def slab_append(self, dev_msg: int, cap_full: int, cap_xonly: int):
         self._ck(self._L.dsl_slab_append(self._h, C.c_void_p(dev_msg), int(cap_full), int(cap_xonly)))
 
+    def slab_append2(self, dev_msg_a: int, dev_msg_b: int, cap_full: int, cap_xonly: int):
+        self._ck(self._L.dsl_slab_append2(self._h, C.c_void_p(dev_msg_a or None), C.c_void_p(dev_msg_b or None),
+                                          int(cap_full), int(cap_xonly)))
+
     def slab_status(self, reset_high_water: bool = False):
         """(overflow, band_missed, high-water full, high-water position-only); blocking"""
         st = (C.c_int32 * 4)()

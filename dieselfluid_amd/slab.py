@@ -55,6 +55,7 @@ class HipSlabEngine:
         # kernels and NCCL ops are ordered through torch's current stream
         self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.supports_split = params.math_mode == 1
+        self.appends_pairs = True
         self.comm_stream = torch.cuda.Stream(self.dev) if self.supports_split else None
 
     def set_caps(self, cap_full: int, cap_x: int):
@@ -90,11 +91,13 @@ class HipSlabEngine:
     def force_inner(self):
         self.eng.force_pass_split(SPLIT_INNER)
 
-    def append(self, msg: torch.Tensor):
-        m = msg if msg.device == self.dev else msg.to(self.dev)
+    def append(self, msg: torch.Tensor, msg2: torch.Tensor = None):
+        """one or both neighbours' messages, one launch"""
+        ms = [None if m is None else (m if m.device == self.dev else m.to(self.dev)).contiguous() for m in (msg, msg2)]
         # the engine runs on torch's current stream, so the caching allocator's stream-ordered
-        # reuse keeps m's memory valid until the append kernel has run
-        self.eng.slab_append(m.contiguous().data_ptr(), self.cap_full, self.cap_x)
+        # reuse keeps the messages' memory valid until the append kernel has run
+        self.eng.slab_append2(ms[0].data_ptr() if ms[0] is not None else 0,
+                              ms[1].data_ptr() if ms[1] is not None else 0, self.cap_full, self.cap_x)
 
     def status(self, reset_high_water: bool = False):
         return self.eng.slab_status(reset_high_water)
@@ -175,9 +178,12 @@ class SlabDriver:
         for w in works:
             w.wait()
         nbs = self._neighbours()
-        for k in range(2):
-            if nbs[k] is not None:
-                self.engine.append(self._recv[k][:n])
+        got = [self._recv[k][:n] for k in range(2) if nbs[k] is not None]
+        if len(got) == 2 and getattr(self.engine, "appends_pairs", False):
+            self.engine.append(got[0], got[1])
+        else:
+            for m in got:
+                self.engine.append(m)
         self._ghosts_in = True
 
     def exchange(self):

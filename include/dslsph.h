@@ -286,6 +286,9 @@ int dsl_slab_pack_band(dsl_handle *h, float width_full, float *dev_lo, float *de
                        void *stream);
 int dsl_force_pass_split(dsl_handle *h, int phase);
 int dsl_slab_append(dsl_handle *h, const float *dev_message, int cap_full, int cap_xonly);
+/* both neighbours' messages in one launch (either may be NULL); b lands behind a */
+int dsl_slab_append2(dsl_handle *h, const float *dev_message_a, const float *dev_message_b, int cap_full,
+                     int cap_xonly);
 int dsl_slab_status(dsl_handle *h, int32_t status[4], int reset_high_water);
 int dsl_slab_overflow(dsl_handle *h, int *high_water);
 int dsl_get_count(dsl_handle *h, int *n_live, int *n_owned); /* blocking */
