@@ -128,9 +128,19 @@ def main():
         engines = [eng]
     else:
         from dieselfluid_amd import slab
-        drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank,
+        def pci_params(p):
+            p.pci_max_iters = args.pci_iters
+            p.eos_w = p.eos_w / args.pci_iters
+            p.delta = 1.0e-7
+            if args.extra_terms:
+                p.xsph_eps = 0.25
+                p.st_kappa = 25.0 * p.h * p.h
+
+        pci = args.method == "pcisph"
+        drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank, pcisph=pci,
+                                       params_hook=pci_params if pci else None,
                                        overlap=False if args.no_overlap else None)
-        step = drv.wcsph_step
+        step = drv.pcisph_step if pci else drv.wcsph_step
         engines = [drv.engine_core]
 
     def barrier():

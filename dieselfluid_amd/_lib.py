@@ -93,6 +93,10 @@ EXPORTS = {
     "dsl_download_cell_start": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_slab_config": (C.c_int, [_vp, C.c_int, C.c_float, C.c_float]),
     "dsl_slab_message_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "dsl_slab_record_floats": (C.c_int, [_vp]),
+    "dsl_slab_message_floats_for": (C.c_size_t, [_vp, C.c_int, C.c_int]),
+    "dsl_pcisph_phase": (C.c_int, [_vp, C.c_int]),
+    "dsl_pcisph_error_word": (C.c_int, [_vp, _vp, C.c_int]),
     "dsl_slab_split": (C.c_int, [_vp, C.c_float, C.c_float]),
     "dsl_slab_pack": (C.c_int, [_vp, C.c_float, C.c_float, _vp, _vp, C.c_int, C.c_int]),
     "dsl_slab_pack_band": (C.c_int, [_vp, C.c_float, _vp, _vp, C.c_int, C.c_int, _vp]),

@@ -50,6 +50,7 @@ struct dsl_handle {
   // split slab step (dsl_force_pass_split): band tiles first, interior tiles after the pack
   float split_margin = 0.0f, split_width = 0.0f;
   bool split_pending = false;
+  bool pci_split_guard = false;  // between DSL_PCI_BEGIN_STEP and DSL_PCI_END_STEP
   hipEvent_t ev_band = nullptr;
   // DSL_NEIGH_LSH_REF
   bool lsh = false;
@@ -1249,7 +1250,7 @@ int dsl_wcsph_step(dsl_handle* h, int nsteps) {
 int dsl_pcisph_begin(dsl_handle* h) {
   CHECK_HANDLE(h);
   if (int rc = alloc_pci(h)) return rc;
-  const size_t n = (size_t)h->n;
+  const size_t n = (size_t)h->cap;  // (slab mode keeps the live count on the device: copy every slot)
   for (int k = 0; k < 6; ++k)
     HIP_TRY(h, hipMemcpyAsync(h->pci[h->cur_pci][k], h->pv[h->cur_pv][k], n * sizeof(float), hipMemcpyDeviceToDevice,
                               h->stream));
@@ -1257,92 +1258,148 @@ int dsl_pcisph_begin(dsl_handle* h) {
   return DSL_OK;
 }
 
+namespace {
+// FAST mode: LDS-tiled sweeps; the gradient term (a function of x and rho only,
+// field_types.go:39-42) is identical in every correction iteration, so it is swept once
+// and re-added.  The running-mass viscosity recurrence for m != 1 needs the branching kernel.
+bool pci_tiled(const dsl_handle* h) {
+  return h->prm.math_mode == DSL_MATH_FAST && !(h->c.visc_running_mass && h->c.mass != 1.0f);
+}
+bool pci_extra_terms(const dsl_handle* h) { return h->c.xsph_eps != 0.0f || h->c.st_kappa != 0.0f; }
+
+// NN, DensityAll, ViscousAll (pcisph_darwin.go:43-45) and the loop set-up
+int pci_begin_step(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  if (int rc = build_grid(h, false)) return rc;
+  if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
+  if (int rc = materialise_forces(h)) return rc;
+  if (int rc = materialise_press(h)) return rc;
+  CSoa3 p = cpos(h), v = cvel(h);
+  Soa3 F = mfrc(h);
+  CSoa3 cF{F.x, F.y, F.z};
+  const bool XS = pci_extra_terms(h);
+  if (pci_tiled(h)) {
+    Soa3 G{h->gterm[0], h->gterm[1], h->gterm[2]};
+    Soa3 none{nullptr, nullptr, nullptr};
+    Soa3 xs{h->xsph[0], h->xsph[1], h->xsph[2]};
+    int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45 (+ cohesion, XSPH sums)
+      if (XS)
+        hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
+                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+      else
+        hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
+                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+    });
+    if (rc) return rc;
+    rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
+      hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
+                         dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
+                         h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+    });
+    if (rc) return rc;
+  } else {
+    if (int rc = viscous_pass(h, XS ? 1 : 0)) return rc;
+  }
+  hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats);
+  HIP_TRY(h, hipGetLastError());
+  return DSL_OK;
+}
+
+// one correction iteration up to (not including) the convergence check :52-94
+int pci_iterate(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  dim3 g(grid_for(launch_n(h))), b(kBlock);
+  CSoa3 p = cpos(h);
+  Soa3 F = mfrc(h);
+  CSoa3 cF{F.x, F.y, F.z};
+  Soa3 pp = mpcip(h), pvv = mpciv(h);
+  int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
+    hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, cF, pp, pvv, h->dstats);
+  });
+  if (rc) return rc;
+  CSoa3 cpp{pp.x, pp.y, pp.z};
+  const bool tiled = pci_tiled(h);
+  rc = timed(h, DSL_K_PCI_DENSITY, [&] {
+    if (tiled)
+      hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                         h->tiles, h->n_tiles, h->cell_start, p, cpp, h->press, h->dstats);
+    else
+      by_math(h, [&](auto fast) {
+        hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), p, cpp,
+                           h->press, h->dstats);
+      });
+  });
+  if (rc) return rc;
+  if (tiled) {
+    CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
+    rc = timed(h, DSL_K_GRADIENT, [&] {
+      hipLaunchKernelGGL(k_pci_add_gradient, g, b, 0, h->stream, c, cG, F, h->dstats);
+    });
+    if (rc) return rc;
+  } else if ((rc = gradient_pass(h, 1))) {      // GradientPressureForce :93
+    return rc;
+  }
+  return DSL_OK;
+}
+
+int pci_check(dsl_handle* h) {                   // :95-98
+  hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, h->c, h->dstats);
+  HIP_TRY(h, hipGetLastError());
+  return DSL_OK;
+}
+
+int pci_end_step(dsl_handle* h) {                // Update :101 (positions advect with v + XSPH)
+  if (int rc = update_pass(h, pci_extra_terms(h))) return rc;
+  h->steps++;
+  return DSL_OK;
+}
+}  // namespace
+
 int dsl_pcisph_step(dsl_handle* h, int nsteps) {
   CHECK_HANDLE(h);
-  if (h->c.n_ptr) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_pcisph_step: slabs are implemented for the WCSPH step only");
+  if (h->c.n_ptr)
+    return fail(h, DSL_ERR_UNSUPPORTED,
+                "dsl_pcisph_step: in slab mode drive the step with dsl_pcisph_phase (the iteration error is global)");
   if (!h->pci_active) {
     if (int rc = dsl_pcisph_begin(h)) return rc;
   }
-  const DevConsts& c = h->c;
-  dim3 g(grid_for(h->n)), b(kBlock);
-  // FAST mode: LDS-tiled sweeps; the gradient term (a function of x and rho only,
-  // field_types.go:39-42) is identical in every correction iteration, so it is swept once
-  // and re-added.  The running-mass viscosity recurrence for m != 1 needs the branching kernel.
-  const bool tiled = h->prm.math_mode == DSL_MATH_FAST && !(c.visc_running_mass && c.mass != 1.0f);
   for (int s = 0; s < nsteps; ++s) {
-    if (int rc = build_grid(h, false)) return rc;
-    if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
-    if (int rc = materialise_forces(h)) return rc;
-    if (int rc = materialise_press(h)) return rc;
-    CSoa3 p = cpos(h), v = cvel(h);
-    Soa3 F = mfrc(h);
-    CSoa3 cF{F.x, F.y, F.z};
-    const bool XS = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
-    if (tiled) {
-      Soa3 G{h->gterm[0], h->gterm[1], h->gterm[2]};
-      Soa3 none{nullptr, nullptr, nullptr};
-      Soa3 xs{h->xsph[0], h->xsph[1], h->xsph[2]};
-      int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45 (+ cohesion, XSPH sums)
-        if (XS)
-          hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
-                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                             h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
-        else
-          hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
-                             dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                             h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
-      });
-      if (rc) return rc;
-      rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
-        hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
-                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
-      });
-      if (rc) return rc;
-    } else {
-      if (int rc = viscous_pass(h, XS ? 1 : 0)) return rc;
-    }
-    hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats);
+    if (int rc = pci_begin_step(h)) return rc;
     for (int it = 0; it < h->prm.pci_max_iters; ++it) {
-      Soa3 pp = mpcip(h), pvv = mpciv(h);
-      int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
-        hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, cF, pp, pvv, h->dstats);
-      });
-      if (rc) return rc;
-      CSoa3 cpp{pp.x, pp.y, pp.z};
-      rc = timed(h, DSL_K_PCI_DENSITY, [&] {
-        if (tiled)
-          hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                             h->tiles, h->n_tiles, h->cell_start, p, cpp, h->press, h->dstats);
-        else
-          by_math(h, [&](auto fast) {
-            hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), p, cpp,
-                               h->press, h->dstats);
-          });
-      });
-      if (rc) return rc;
-      if (tiled) {
-        CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
-        rc = timed(h, DSL_K_GRADIENT, [&] {
-          hipLaunchKernelGGL(k_pci_add_gradient, g, b, 0, h->stream, c, cG, F, h->dstats);
-        });
-        if (rc) return rc;
-      } else if ((rc = gradient_pass(h, 1))) {      // GradientPressureForce :93
-        return rc;
-      }
-      hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, c, h->dstats);
+      if (int rc = pci_iterate(h)) return rc;
+      if (int rc = pci_check(h)) return rc;
     }
-    HIP_TRY(h, hipGetLastError());
-    if (int rc = update_pass(h, XS)) return rc;     // Update :101 (positions advect with v + XSPH)
-    h->steps++;
+    if (int rc = pci_end_step(h)) return rc;
   }
+  return DSL_OK;
+}
+
+int dsl_pcisph_phase(dsl_handle* h, int phase) {
+  CHECK_HANDLE(h);
+  if (!h->pci_active) return fail(h, DSL_ERR_INVALID, "dsl_pcisph_phase: call dsl_pcisph_begin first");
+  switch (phase) {
+    case DSL_PCI_BEGIN_STEP: h->pci_split_guard = true; return pci_begin_step(h);
+    case DSL_PCI_ITERATE: return pci_iterate(h);
+    case DSL_PCI_CHECK: return pci_check(h);
+    case DSL_PCI_END_STEP: h->pci_split_guard = false; return pci_end_step(h);
+    default: return fail(h, DSL_ERR_INVALID, "dsl_pcisph_phase: bad phase");
+  }
+}
+
+int dsl_pcisph_error_word(dsl_handle* h, uint32_t* dev_word, int store) {
+  CHECK_HANDLE(h);
+  if (!dev_word) return fail(h, DSL_ERR_INVALID, "dsl_pcisph_error_word: null pointer");
+  uint32_t* mine = &h->dstats->pci_cur_err_bits;
+  HIP_TRY(h, hipMemcpyAsync(store ? mine : dev_word, store ? dev_word : mine, sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                            h->stream));
   return DSL_OK;
 }
 
 int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
   CHECK_HANDLE(h);
   if (axis < -1 || axis > 2 || !(lo < hi)) return fail(h, DSL_ERR_INVALID, "dsl_slab_config: bad axis or empty range");
-  if (h->pci_active) return fail(h, DSL_ERR_UNSUPPORTED, "slabs are implemented for the WCSPH step only");
   if (h->lsh) return fail(h, DSL_ERR_UNSUPPORTED, "lsh_ref buckets are angular cones through the whole domain: no slabs");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
@@ -1366,6 +1423,13 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
 size_t dsl_slab_message_floats(int cap_full, int cap_xonly) {
   if (cap_full < 0 || cap_xonly < 0) return 0;
   return (size_t)(cap_full + 1) * kRecord + (size_t)cap_xonly * kRecordX;
+}
+
+int dsl_slab_record_floats(dsl_handle* h) { return h && h->pci_active ? kRecordPci : kRecord; }
+
+size_t dsl_slab_message_floats_for(dsl_handle* h, int cap_full, int cap_xonly) {
+  if (cap_full < 0 || cap_xonly < 0) return 0;
+  return (size_t)(cap_full + 1) * dsl_slab_record_floats(h) + (size_t)cap_xonly * kRecordX;
 }
 
 namespace {
@@ -1439,8 +1503,15 @@ int slab_pack_on(dsl_handle* h, hipStream_t st, float width_full, float width, b
                      dev_hi ? 1 : 0, h->pack_counts);
   hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(kOffsBlock), 0, st, h->pack_counts, nblk, dev_lo, dev_hi, cap_full,
                      cap_x, h->dn + 5);
+  CSoa3 pcip{nullptr, nullptr, nullptr}, pciv{nullptr, nullptr, nullptr};
+  if (h->pci_active) {  // migrants take their predictor state along
+    Soa3 a = mpcip(h), b = mpciv(h);
+    pcip = CSoa3{a.x, a.y, a.z};
+    pciv = CSoa3{b.x, b.y, b.z};
+  }
   hipLaunchKernelGGL(k_slab_write, dim3(nblk), dim3(kBlock), 0, st, h->c, sb, old_axis, pa, p.x, p.y, p.z, v.x, v.y, v.z,
-                     h->ids[h->cur_ids], dev_lo, dev_hi, cap_full, cap_x, h->pack_counts);
+                     h->ids[h->cur_ids], dev_lo, dev_hi, cap_full, cap_x, h->pack_counts, dsl_slab_record_floats(h), pcip,
+                     pciv);
   HIP_TRY(h, hipGetLastError());
   return DSL_OK;
 }
@@ -1502,12 +1573,18 @@ int dsl_slab_append2(dsl_handle* h, const float* dev_message_a, const float* dev
   if ((!dev_message_a && !dev_message_b) || cap_full < 0 || cap_xonly < 0)
     return fail(h, DSL_ERR_INVALID, "dsl_slab_append: bad argument");
   if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: a split force pass is in flight");
+  if (h->pci_active && h->pci_split_guard) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: PCISPH step in flight");
   if (!h->forces_uniform) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: forces must be uniform (dsl_reset_forces)");
   if (cap_full + cap_xonly == 0) return DSL_OK;
   Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
+  Soa3 pcip{nullptr, nullptr, nullptr}, pciv{nullptr, nullptr, nullptr};
+  if (h->pci_active) {
+    pcip = mpcip(h);
+    pciv = mpciv(h);
+  }
   hipLaunchKernelGGL(k_slab_append, dim3(grid_for(cap_full + cap_xonly), 2), dim3(kBlock), 0, h->stream, dev_message_a,
                      dev_message_b, cap_full, cap_xonly, h->dn, h->cap, p.x, p.y, p.z, v.x, v.y, v.z,
-                     h->ids[h->cur_ids], h->dn + 5);
+                     h->ids[h->cur_ids], h->dn + 5, dsl_slab_record_floats(h), pcip, pciv);
   hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message_a, dev_message_b, cap_full, cap_xonly,
                      h->dn, h->cap);
   HIP_TRY(h, hipGetLastError());

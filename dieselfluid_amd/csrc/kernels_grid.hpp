@@ -216,20 +216,22 @@ __global__ __launch_bounds__(kBlock) void k_pack1(int n, float* __restrict__ sta
 // ---------------------------------------------------------------------------------
 // slab halo: band selection (wave-aggregated append) and record append
 // ---------------------------------------------------------------------------------
-constexpr int kRecord = 7;   // full record: x,y,z,vx,vy,vz,id-bits
-constexpr int kRecordX = 3;  // position-only record: x,y,z
+constexpr int kRecord = 7;      // full record: x,y,z,vx,vy,vz,id-bits
+constexpr int kRecordPci = 13;  // ... + the PCISPH predictor state (_pos, _vel) once dsl_pcisph_begin has run
+constexpr int kRecordX = 3;     // position-only record: x,y,z
 
-// Message layout (floats): header of kRecord words ([0] = full-record count, [1] =
-// position-only count, int bits), cap_full full records, cap_x position-only records.
+// Message layout (floats): header of `rec` words ([0] = full-record count, [1] =
+// position-only count, int bits), cap_full full records of `rec` words (rec = kRecord or
+// kRecordPci), cap_x position-only records.
 // Particles within width_full of the plane (and migrants beyond it) travel as full records;
 // the rest of the band only feeds the receiver's ghost densities and travels as positions.
 struct SlabBands {
   float full_lo, band_lo;  // lo side: p < full_lo -> full record, else p < band_lo -> position only
   float full_hi, band_hi;  // hi side: p >= full_hi -> full record, else p >= band_hi -> position only
 };
-__device__ __forceinline__ float* slab_full_record(float* msg, int k) { return msg + (size_t)(k + 1) * kRecord; }
-__device__ __forceinline__ float* slab_x_record(float* msg, int cap_full, int k) {
-  return msg + (size_t)(cap_full + 1) * kRecord + (size_t)k * kRecordX;
+__device__ __forceinline__ float* slab_full_record(float* msg, int rec, int k) { return msg + (size_t)(k + 1) * rec; }
+__device__ __forceinline__ float* slab_x_record(float* msg, int rec, int cap_full, int k) {
+  return msg + (size_t)(cap_full + 1) * rec + (size_t)k * kRecordX;
 }
 
 // Band selection without atomics (a band is a contiguous slot range in cell order, so per-wave
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(kBlock) void k_slab_write(DevConsts c, SlabBands sb
                                                        const float* __restrict__ vx, const float* __restrict__ vy,
                                                        const float* __restrict__ vz, const int* __restrict__ ids,
                                                        float* __restrict__ out_lo, float* __restrict__ out_hi,
-                                                       int cap_full, int cap_x, const int* __restrict__ block_offsets) {
+                                                       int cap_full, int cap_x, const int* __restrict__ block_offsets,
+                                                       int rec, CSoa3 pcip, CSoa3 pciv) {
   __shared__ int wsum[kBlock / kWave][4];
   const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
   const int base = blockIdx.x * kPackChunk + wid * (kPackIters * kWave);
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_write(DevConsts c, SlabBands sb
         const int d = at + __builtin_popcountll(bal[k][it] & below);
         if (k < 2) {
           if (d < cap_full) {
-            float* r = slab_full_record(msg, d);
+            float* r = slab_full_record(msg, rec, d);
             r[0] = px[i];
             r[1] = py[i];
             r[2] = pz[i];
@@ -405,9 +408,17 @@ __global__ __launch_bounds__(kBlock) void k_slab_write(DevConsts c, SlabBands sb
             r[4] = vy[i];
             r[5] = vz[i];
             r[6] = __int_as_float(ids[i]);
+            if (rec == kRecordPci) {
+              r[7] = pcip.x[i];
+              r[8] = pcip.y[i];
+              r[9] = pcip.z[i];
+              r[10] = pciv.x[i];
+              r[11] = pciv.y[i];
+              r[12] = pciv.z[i];
+            }
           }
         } else if (d < cap_x) {
-          float* r = slab_x_record(msg, cap_full, d);
+          float* r = slab_x_record(msg, rec, cap_full, d);
           r[0] = px[i];
           r[1] = py[i];
           r[2] = pz[i];
@@ -434,7 +445,8 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
                                                         float* __restrict__ px, float* __restrict__ py,
                                                         float* __restrict__ pz, float* __restrict__ vx,
                                                         float* __restrict__ vy, float* __restrict__ vz,
-                                                        int* __restrict__ ids, int* __restrict__ slab_state) {
+                                                        int* __restrict__ ids, int* __restrict__ slab_state, int rec,
+                                                        Soa3 pcip, Soa3 pciv) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
   int nf0 = 0, nx0 = 0, nf1 = 0, nx1 = 0;
   if (msg0) slab_counts(msg0, cap_full, cap_x, nf0, nx0);
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
   const int nf = blockIdx.y == 0 ? nf0 : nf1, nx = blockIdx.y == 0 ? nx0 : nx1;
   const int at = blockIdx.y == 0 ? at0 : at0 + nf0 + nx0;
   if (k < nf) {
-    const float* r = msg + (size_t)(k + 1) * kRecord;
+    const float* r = msg + (size_t)(k + 1) * rec;
     const int d = at + k;
     px[d] = r[0];
     py[d] = r[1];
@@ -458,9 +470,17 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
     vy[d] = r[4];
     vz[d] = r[5];
     ids[d] = __float_as_int(r[6]);
+    if (rec == kRecordPci) {  // a migrant keeps its predictor state (the reference never re-synchronises it)
+      pcip.x[d] = r[7];
+      pcip.y[d] = r[8];
+      pcip.z[d] = r[9];
+      pciv.x[d] = r[10];
+      pciv.y[d] = r[11];
+      pciv.z[d] = r[12];
+    }
   } else if (k >= cap_full && k - cap_full < nx) {
     const int j = k - cap_full;
-    const float* r = msg + (size_t)(cap_full + 1) * kRecord + (size_t)j * kRecordX;
+    const float* r = msg + (size_t)(cap_full + 1) * rec + (size_t)j * kRecordX;
     const int d = at + nf + j;
     px[d] = r[0];
     py[d] = r[1];
@@ -469,6 +489,14 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
     vy[d] = 0.f;
     vz[d] = 0.f;
     ids[d] = -1;
+    if (rec == kRecordPci) {  // ghosts: never predicted, any finite value will do
+      pcip.x[d] = r[0];
+      pcip.y[d] = r[1];
+      pcip.z[d] = r[2];
+      pciv.x[d] = 0.f;
+      pciv.y[d] = 0.f;
+      pciv.z[d] = 0.f;
+    }
   }
 }
 __global__ void k_slab_bump(const float* __restrict__ msg0, const float* __restrict__ msg1, int cap_full, int cap_x,

@@ -9,13 +9,6 @@
 
 namespace dsl {
 
-struct Soa3 {
-  float *x, *y, *z;
-};
-struct CSoa3 {
-  const float *x, *y, *z;
-};
-
 // ---------------------------------------------------------------------------------
 // D: SPHField.Density (model/field/sph_field.go:155-172) for every slot, plus the
 // per-particle pressure term P(rho)/rho^2 of SPHField.Gradient (sph_field.go:192-196,
@@ -569,7 +562,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, Neigh nb, C
     const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
     const float dp = density_error * c.delta;
     press[i] += dp;
-    err_bits = nonneg_bits(abs_err);
+    // slab mode: a ghost's predicted density is meaningless (it sees half a neighbourhood) and must
+    // not decide the iteration's error
+    if (slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
   }
   wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
 }

@@ -854,6 +854,9 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       int srow, off;
       tile_target(m, t, srow, off);
       const int g = m.row_gs[srow] + off;
+      // slab mode: a ghost's predicted density is meaningless (half a neighbourhood, no predictor
+      // state) and must not decide the iteration's error
+      if (!slab_owned(c, p.x[g], p.y[g], p.z[g])) continue;
       const float qx = pp.x[g], qy = pp.y[g], qz = pp.z[g];
       // tile-local cell of the predicted position; the LDS image covers it and its 26
       // neighbours only while it stays inside the tile interior (1..4 per axis)

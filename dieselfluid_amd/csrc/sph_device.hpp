@@ -50,6 +50,14 @@ struct DevConsts {
   const int* n_ptr;
 };
 
+// three SoA component arrays
+struct Soa3 {
+  float *x, *y, *z;
+};
+struct CSoa3 {
+  const float *x, *y, *z;
+};
+
 __device__ __forceinline__ int live_n(const DevConsts& c) { return c.n_ptr ? *c.n_ptr : c.n; }
 
 // Host-visible counters living in device memory (fluid.go:25-26, pcisph_darwin.go:46-98).

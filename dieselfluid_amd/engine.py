@@ -139,7 +139,17 @@ class SPHEngine:
         self._ck(self._L.dsl_slab_config(self._h, int(axis), C.c_float(lo), C.c_float(hi)))
 
     def slab_message_floats(self, cap_full: int, cap_xonly: int) -> int:
-        return int(self._L.dsl_slab_message_floats(int(cap_full), int(cap_xonly)))
+        return int(self._L.dsl_slab_message_floats_for(self._h, int(cap_full), int(cap_xonly)))
+
+    def slab_record_floats(self) -> int:
+        return int(self._L.dsl_slab_record_floats(self._h))
+
+    def pcisph_phase(self, phase: int):
+        """0 begin step, 1 iterate, 2 check, 3 end step (include/dslsph.h)"""
+        self._ck(self._L.dsl_pcisph_phase(self._h, int(phase)))
+
+    def pcisph_error_word(self, dev_word: int, store: bool):
+        self._ck(self._L.dsl_pcisph_error_word(self._h, C.c_void_p(dev_word), 1 if store else 0))
 
     def slab_split(self, width: float, margin: float):
         self._ck(self._L.dsl_slab_split(self._h, C.c_float(width), C.c_float(margin)))

@@ -31,9 +31,12 @@ RECORD_X = 3  # position-only record
 SPLIT_BAND, SPLIT_INNER = 1, 2
 
 
-def message_floats(cap_full: int, cap_x: int) -> int:
+RECORD_PCI = 13  # full record once the PCISPH predictor state travels along
+
+
+def message_floats(cap_full: int, cap_x: int, record: int = RECORD) -> int:
     """header record + full records + position-only records (include/dslsph.h)"""
-    return (cap_full + 1) * RECORD + cap_x * RECORD_X
+    return (cap_full + 1) * record + cap_x * RECORD_X
 
 
 def message_counts(msg: torch.Tensor):
@@ -50,8 +53,7 @@ class HipSlabEngine:
         self.dev = torch.device("cuda", device)
         self.max_full, self.max_x = int(max_scale * cap_full), int(max_scale * cap_x)
         self.cap_full, self.cap_x = int(cap_full), int(cap_x)
-        self._send = [torch.zeros(message_floats(self.max_full, self.max_x), dtype=torch.float32, device=self.dev)
-                      for _ in range(2)]
+        self._send = None  # allocated at the first pack: the record size depends on dsl_pcisph_begin
         # kernels and NCCL ops are ordered through torch's current stream
         self.eng.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.supports_split = params.math_mode == 1
@@ -62,7 +64,16 @@ class HipSlabEngine:
         self.cap_full, self.cap_x = min(int(cap_full), self.max_full), min(int(cap_x), self.max_x)
 
     def message_floats(self) -> int:
-        return message_floats(self.cap_full, self.cap_x)
+        return message_floats(self.cap_full, self.cap_x, self.eng.slab_record_floats())
+
+    def max_message_floats(self) -> int:
+        return message_floats(self.max_full, self.max_x, self.eng.slab_record_floats())
+
+    def _buffers(self):
+        if self._send is None or self._send[0].numel() < self.max_message_floats():
+            self._send = [torch.zeros(self.max_message_floats(), dtype=torch.float32, device=self.dev)
+                          for _ in range(2)]
+        return self._send
 
     def _views(self, want_lo, want_hi):
         n = self.message_floats()
@@ -71,8 +82,9 @@ class HipSlabEngine:
     # -- protocol -------------------------------------------------------------------
     def pack(self, width_full: float, width: float, want_lo: bool, want_hi: bool):
         """Asynchronous: both band messages are filled on the device, counts included."""
-        self.eng.slab_pack(width_full, width, self._send[0].data_ptr() if want_lo else 0,
-                           self._send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x)
+        send = self._buffers()
+        self.eng.slab_pack(width_full, width, send[0].data_ptr() if want_lo else 0,
+                           send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x)
         return self._views(want_lo, want_hi)
 
     def split(self, width: float, margin: float):
@@ -83,8 +95,9 @@ class HipSlabEngine:
 
     def pack_band(self, width_full: float, want_lo: bool, want_hi: bool):
         """on comm_stream, which the library makes wait for the band phase only"""
-        self.eng.slab_pack_band(width_full, self._send[0].data_ptr() if want_lo else 0,
-                                self._send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x,
+        send = self._buffers()
+        self.eng.slab_pack_band(width_full, send[0].data_ptr() if want_lo else 0,
+                                send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x,
                                 self.comm_stream.cuda_stream)
         return self._views(want_lo, want_hi)
 
@@ -161,8 +174,9 @@ class SlabDriver:
         nbs = self._neighbours()
         n = self.engine.message_floats()
         if self._recv is None or self._recv[0].numel() < n:
-            full = message_floats(getattr(self.engine, "max_full", self.engine.cap_full),
-                                  getattr(self.engine, "max_x", self.engine.cap_x))
+            full = (self.engine.max_message_floats() if hasattr(self.engine, "max_message_floats") else
+                    message_floats(getattr(self.engine, "max_full", self.engine.cap_full),
+                                   getattr(self.engine, "max_x", self.engine.cap_x)))
             self._recv = [torch.zeros(max(full, n), dtype=torch.float32, device=self.comm_dev) for _ in range(2)]
         sbuf = [None if s is None else (s if s.device == self.comm_dev else s.to(self.comm_dev)) for s in send]
         ops = []
@@ -227,6 +241,40 @@ class SlabDriver:
             if self.world > 1 and self.steps % self.REPLAN_EVERY == 0:
                 self._replan()
 
+    def pcisph_step(self, nsteps: int = 1):
+        """PCISPH across slabs.  DensityF uses the neighbours' CURRENT positions and the ghosts'
+        densities are recomputed locally, so the correction iterations need no halo exchange; what
+        has to be global is the iteration's max density error (the early-out of
+        pcisph_darwin.go:95-98), one 4-byte MAX all-reduce per iteration.  Migrants carry their
+        predictor state in the message (13-float records)."""
+        e = self.engine
+        core = self.engine_core
+        iters = int(core.params.pci_max_iters)
+        if getattr(self, "_err", None) is None:
+            self._err = torch.zeros(1, dtype=torch.int32, device=e.dev)
+        for _ in range(nsteps):
+            if not self._ghosts_in:
+                self.exchange()
+            self._ghosts_in = False
+            core.pcisph_phase(0)            # NN, DensityAll, ViscousAll
+            for _it in range(iters):
+                core.pcisph_phase(1)        # predict, DensityF, gradient force
+                if self.world > 1:
+                    core.pcisph_error_word(self._err.data_ptr(), store=False)
+                    if self.comm_dev.type == "cuda":
+                        dist.all_reduce(self._err, op=dist.ReduceOp.MAX, group=self.group)
+                    else:
+                        t = self._err.cpu()
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                        self._err.copy_(t)
+                    core.pcisph_error_word(self._err.data_ptr(), store=True)
+                core.pcisph_phase(2)        # convergence check
+            core.pcisph_phase(3)            # Update; ghosts are marked for removal
+            self.exchange()
+            self.steps += 1
+            if self.world > 1 and self.steps % self.REPLAN_EVERY == 0:
+                self._replan()
+
     # -- validation helper ---------------------------------------------------------------
     def gather_state(self, n_total: int):
         """Owned particles of every rank assembled by global id on rank 0 (tests only)."""
@@ -249,12 +297,15 @@ class SlabDriver:
     # -- the bench / test scene ---------------------------------------------------------------
     @classmethod
     def dambreak(cls, n3: int, math_mode: int = 1, device: int = 0, axis: int = 2, rank=None, world=None,
-                 engine_factory=None, group=None, vel_fn=None, overlap=None, tile_align=True, **scene_kw):
+                 engine_factory=None, group=None, vel_fn=None, overlap=None, tile_align=True, params_hook=None,
+                 pcisph=False, **scene_kw):
         """Dam-break of n3^3 particles split into `world` slabs along `axis` (default z: the
         collapse is symmetric in z, so the slabs stay balanced without re-planning)."""
         rank = dist.get_rank(group) if rank is None else rank
         world = dist.get_world_size(group) if world is None else world
         p, _ = scenes.dambreak_scene(n3, math_mode=math_mode, positions=False, **scene_kw)
+        if params_hook is not None:
+            params_hook(p)
         L = p.box_max[2]
         dx = L / n3
         h = p.h
@@ -299,6 +350,9 @@ class SlabDriver:
             eng.upload("velocities", np.ascontiguousarray(vel_fn(ids, pos), dtype=np.float32))
         eng.set_ids(ids)
         eng.reset_forces()
+        if pcisph:
+            eng.pcisph_begin()  # predictor state = the initial positions / velocities (pcisph_darwin.go:28-41)
+            overlap = False     # the PCISPH step has no split force pass
         drv = cls(engine, rank, world, axis, planes, width, width_full, group=group, overlap=overlap, margin=margin)
         eng.slab_config(axis, drv.lo, drv.hi)
         if drv.overlap:

@@ -210,6 +210,21 @@ int dsl_field_interpolate(dsl_handle *h, int scalar_buffer, const float *host_po
 int dsl_wcsph_step(dsl_handle *h, int nsteps);
 int dsl_pcisph_begin(dsl_handle *h); /* pcisph_darwin.go:28-41 predictor copies */
 int dsl_pcisph_step(dsl_handle *h, int nsteps);
+/* The same step in pieces, for hosts that have to look at the iteration error between the
+ * correction sweep and the convergence check (pcisph_darwin.go:95-98) -- slab mode, where the
+ * error is the maximum over all ranks:
+ *   DSL_PCI_BEGIN_STEP  NN, DensityAll, ViscousAll, loop set-up        (:43-51)
+ *   DSL_PCI_ITERATE     predict, DensityF + pressure accumulate, gradient force (:52-94); leaves
+ *                       this handle's max density error in a device word
+ *   DSL_PCI_CHECK       the early-out test of that word (:95-98); later ITERATEs are no-ops
+ *                       once it has passed
+ *   DSL_PCI_END_STEP    Update (:101)
+ * dsl_pcisph_error_word copies the device word out (store = 0) or in (store = 1), device to
+ * device and asynchronously; its bits order like the non-negative float they hold, so a MAX
+ * all-reduce over uint32 is the global error. */
+enum { DSL_PCI_BEGIN_STEP = 0, DSL_PCI_ITERATE = 1, DSL_PCI_CHECK = 2, DSL_PCI_END_STEP = 3 };
+int dsl_pcisph_phase(dsl_handle *h, int phase);
+int dsl_pcisph_error_word(dsl_handle *h, uint32_t *dev_word, int store);
 
 int dsl_get_stats(dsl_handle *h, dsl_stats *out);
 int dsl_sync(dsl_handle *h); /* Queue.Finish() pcisph_gpu_darwin.go:261,271 */
@@ -278,6 +293,10 @@ int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
  *   reports a violation). */
 enum { DSL_SPLIT_BAND = 1, DSL_SPLIT_INNER = 2 };
 size_t dsl_slab_message_floats(int cap_full, int cap_xonly);
+/* Once dsl_pcisph_begin has run, a full record also carries the predictor state (_pos, _vel of
+ * pcisph_darwin.go:28-41, which the reference never re-synchronises): 13 floats instead of 7. */
+int dsl_slab_record_floats(dsl_handle *h);
+size_t dsl_slab_message_floats_for(dsl_handle *h, int cap_full, int cap_xonly);
 int dsl_slab_config(dsl_handle *h, int axis, float lo, float hi);
 int dsl_slab_split(dsl_handle *h, float width, float margin);
 int dsl_slab_pack(dsl_handle *h, float width_full, float width, float *dev_lo, float *dev_hi, int cap_full,

@@ -102,3 +102,83 @@ def test_split_step_flags_a_margin_violation(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), 1, 32, True, 8.0, out), nprocs=2, join=True)
     z = np.load(out)
     assert np.any(z["info"][:, 3] == 1)
+
+
+# ---- PCISPH across slabs (BASELINE configs[4]'s 8-GPU form) ---------------------------------
+
+def _pci_params(p, extra):
+    p.pci_max_iters = 4
+    p.eos_w = p.eos_w / 4          # as bench.py: the EOS gradient is added once per iteration
+    p.delta = 1.0e-7
+    p.pci_max_error = 1.0          # reached in the 16^3 cases (early-out after one iteration), not in the 24^3 one
+    if extra:
+        p.xsph_eps = 0.25
+        p.st_kappa = 25.0 * p.h * p.h
+
+
+def _pci_worker(rank, world, port, math_mode, n3, extra, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
+    torch.cuda.set_device(0)
+    from dieselfluid_amd.slab import SlabDriver
+    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=2, pcisph=True,
+                              params_hook=lambda p: _pci_params(p, extra),
+                              vel_fn=lambda ids, pos: 0.5 * _vel_fn(ids, pos, axis=2))
+    assert drv.engine.eng.slab_record_floats() == 13
+    drv.pcisph_step(STEPS)
+    res = drv.gather_state(n3 ** 3)
+    st = drv.engine.status()
+    stats = drv.engine_core.stats()
+    info = [None] * world if rank == 0 else None
+    dist.gather_object((drv.engine_core.n_owned(), st[0], stats.pci_iters, stats.pci_max_error), info, dst=0)
+    if rank == 0:
+        gp, gv, seen = res
+        np.savez(out, pos=gp, vel=gv, seen=seen, info=np.array(info, dtype=np.float64))
+    dist.destroy_process_group()
+
+
+def _pci_single(n3, math_mode, extra, shuffle=False):
+    from dieselfluid_amd import SPHEngine, scenes
+    p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+    _pci_params(p, extra)
+    if shuffle:
+        for a in range(3):
+            p.grid_min[a] -= 0.37 * p.h
+    vel = 0.5 * _vel_fn(np.arange(n3 ** 3), pos, 2)
+    perm = np.random.default_rng(0).permutation(n3 ** 3) if shuffle else np.arange(n3 ** 3)
+    eng = SPHEngine(p)
+    eng.upload("positions", pos[perm])
+    eng.upload("velocities", vel[perm])
+    eng.reset_forces()
+    eng.pcisph_begin()
+    eng.pcisph_step(STEPS)
+    inv = np.argsort(perm)
+    st = eng.stats()
+    return eng.download("positions")[inv], eng.download("velocities")[inv], st.pci_iters, st.pci_max_error
+
+
+@pytest.mark.parametrize("math_mode,world,n3,extra", [(0, 2, 16, False), (1, 2, 16, True), (1, 3, 24, True)])
+def test_pcisph_slabs_match_single_engine(tmp_path, math_mode, world, n3, extra):
+    out = str(tmp_path / "slab_pci.npz")
+    mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out), nprocs=world, join=True)
+    z = np.load(out)
+    info = z["info"]
+    assert np.all(z["seen"] == 1)
+    assert info[:, 0].sum() == n3 ** 3                      # every particle owned exactly once
+    assert np.all(info[:, 1] == 0)                          # no message / capacity overflow
+    assert len(set(info[:, 2].tolist())) == 1               # every rank ran the same number of iterations
+    assert np.allclose(info[:, 3], info[0, 3], rtol=0, atol=0)  # ... on the same, global, error
+    pos, vel, iters, err = _pci_single(n3, math_mode, extra)
+    assert int(info[0, 2]) == iters
+    assert abs(info[0, 3] - err) <= 1e-3 * max(err, 1e-6)
+    pos_s, vel_s, _, _ = _pci_single(n3, math_mode, extra, shuffle=True)
+    tol_x = max(4e-6, 5.0 * helpers.rel_err(pos_s, pos))
+    tol_v = max(1e-4, 5.0 * helpers.rel_err(vel_s, vel))
+    ex, ev = helpers.rel_err(z["pos"], pos), helpers.rel_err(z["vel"], vel)
+    print(f"pcisph slab-vs-single x {ex:.2e} (tol {tol_x:.2e})  v {ev:.2e} (tol {tol_v:.2e})  iters {iters} err {err:.3e}")
+    assert ex < tol_x
+    assert ev < tol_v
