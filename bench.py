@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the whole force pass")
     ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
 
 
