@@ -19,7 +19,6 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -422,7 +421,6 @@ void poll_tile_stats(dsl_handle* h) {
   if (!h->tstats_pending || hipEventQuery(h->ev_tstats) != hipSuccess) return;
   h->tstats_pending = false;
   h->share_short = (long long)h->host_tstats[5] * 12 > (long long)h->host_tstats[0];
-  if (const char* e = std::getenv("DSL_SHARE_SHORT")) h->share_short = e[0] == '1';  // measurement override
 }
 
 int density_pass(dsl_handle* h) {
