@@ -479,7 +479,14 @@ int force_integrate(dsl_handle* h, int part = 0) {
   if (use_tiled(h)) {
     poll_tile_stats(h);
     rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
-      dim3 g(persistent_grid(h, 2)), b(kTBlock);
+      int gsz = persistent_grid(h, 2);
+      // Two of these workgroups fill a CU's vector registers, and a persistent grid keeps them
+      // filled until it ends: the band pack and the transfer kernels that are meant to run UNDER
+      // the interior launch would not get a wave in before it is over (measured: a 7 us kernel
+      // took 83 us).  The interior launch therefore leaves one workgroup slot free on an eighth
+      // of the CUs (+6 % on its own time).
+      if (part == 2 && gsz >= 64) gsz = (gsz - gsz / 8) & ~7;
+      dim3 g(gsz), b(kTBlock);
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_count(DevConsts c, SlabBands sb
 // one block: exclusive scan of block_counts (in place) per category, then the two headers;
 // overflows and high-water marks are kept for the host to find later.
 // slab_state: [0] overflow, [1] high water full, [2] high water position-only
-constexpr int kOffsBlock = 1024;
+constexpr int kOffsBlock = 256;  // one wave per SIMD: fits next to a resident tile workgroup (split step)
 __global__ __launch_bounds__(kOffsBlock) void k_slab_offsets(int* __restrict__ block_counts, int nblk, float* out_lo,
                                                              float* out_hi, int cap_full, int cap_x,
                                                              int* __restrict__ slab_state) {

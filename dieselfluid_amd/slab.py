@@ -94,11 +94,12 @@ class HipSlabEngine:
         self.eng.force_pass_split(SPLIT_BAND)
 
     def pack_band(self, width_full: float, want_lo: bool, want_hi: bool):
-        """on comm_stream, which the library makes wait for the band phase only"""
+        """On the engine's own stream, between the two force launches: three small kernels that take
+        25 us there.  On a side stream, under the interior launch, they were starved (two tile
+        workgroups fill a CU's registers) and ate the whole window that is meant for the transfer."""
         send = self._buffers()
         self.eng.slab_pack_band(width_full, send[0].data_ptr() if want_lo else 0,
-                                send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x,
-                                self.comm_stream.cuda_stream)
+                                send[1].data_ptr() if want_hi else 0, self.cap_full, self.cap_x, 0)
         return self._views(want_lo, want_hi)
 
     def force_inner(self):
@@ -144,8 +145,8 @@ class SlabDriver:
     """Runs the WCSPH step on one slab and exchanges the 2h band with the two neighbours.
 
     The exchange for step t+1 happens at the END of step t.  With an engine that supports the
-    split force pass it is started as soon as the tiles near the planes are integrated and
-    runs (pack, RCCL send/recv) on a side stream while the interior tiles are integrated."""
+    split force pass the bands are packed as soon as the cell layers near the planes are
+    integrated, and the RCCL send/recv runs on a side stream while the other layers are."""
 
     REPLAN_EVERY = 8  # steps between message-size re-plans (one host sync + one tiny all-reduce)
 
@@ -228,9 +229,10 @@ class SlabDriver:
             if self.world == 1:
                 e.force_pass()
             elif self.overlap:
-                e.force_band()       # owned particles of the tiles near the planes
+                e.force_band()       # owned particles of the cell layers near the planes
+                send = e.pack_band(self.width_full, lo_nb is not None, hi_nb is not None)
+                e.comm_stream.wait_stream(torch.cuda.current_stream())  # ... the pack, not what follows
                 with torch.cuda.stream(e.comm_stream):
-                    send = e.pack_band(self.width_full, lo_nb is not None, hi_nb is not None)
                     posted = self._post(send)
                 e.force_inner()      # the rest, concurrently with the transfer
                 self._finish(posted)

@@ -285,8 +285,14 @@ int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
  *   dsl_slab_split(h, width, margin) once; then per step, after the density pass,
  *   dsl_force_pass_split(h, DSL_SPLIT_BAND)   force+integrate for the particles of the grid-cell
  *                                             layers that reach within width+margin of a plane,
- *   dsl_slab_pack_band(h, ..., stream)        packs the integrated band on `stream` (which is
- *                                             made to wait for the band phase only),
+ *   dsl_slab_pack_band(h, ..., stream)        packs the integrated band.  stream = NULL: on the
+ *                                             handle's stream, between the two launches (three
+ *                                             small kernels, 25 us; the host then lets its
+ *                                             transfer stream wait for that point).  A side
+ *                                             stream is made to wait for the band phase only,
+ *                                             but small kernels issued next to the interior
+ *                                             launch are starved by it (two of its workgroups
+ *                                             fill a CU's vector registers).
  *   dsl_force_pass_split(h, DSL_SPLIT_INNER)  the remaining layers, concurrently with the
  *                                             transfer the host started on `stream`.
  *   `margin` must exceed the distance a particle can move in one step (dsl_slab_status[1]
