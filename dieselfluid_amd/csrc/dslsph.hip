@@ -58,11 +58,13 @@ struct dsl_handle {
   int *bucket_of = nullptr, *lsh_table = nullptr, *lsh_len = nullptr, *lsh_samples = nullptr;
   TileGrid tg{};
   int *tiles = nullptr, *n_tiles = nullptr;
-  // tile statistics read back without ever waiting for them: [0] non-empty tiles, [5] tiles with a
-  // short last pass -> which instantiation of the tiled kernels the next launches use
-  int* host_tstats = nullptr;
-  hipEvent_t ev_tstats = nullptr;
-  bool tstats_pending = false, share_short = false;
+  // tile statistics the density kernel leaves in host-mapped memory, never waited for: [0] non-empty
+  // tiles, [1] tiles with a short last pass, [2] sequence number -> which instantiation of the tiled
+  // kernels the next launches use
+  volatile int* host_tstats = nullptr;
+  int* dev_tstats = nullptr;
+  int tstats_seq = 0, tstats_seen = 0;
+  bool share_short = false;
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -375,11 +377,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
                          h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr);
     });
     if (rc) return rc;
-    if (h->host_tstats && !h->tstats_pending) {
-      HIP_TRY(h, hipMemcpyAsync(h->host_tstats, h->n_tiles, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(h, hipEventRecord(h->ev_tstats, h->stream));
-      h->tstats_pending = true;
-    }
+
   }
   if (h->c.n_ptr && h->prm.math_mode != DSL_MATH_FAST) {
     // the sort has dropped the stale ghosts; the live count stays on the device (FAST: k_tile_list did it)
@@ -418,9 +416,11 @@ int persistent_grid(const dsl_handle* h, int blocks_per_cu) {
 // Which instantiation runs follows the tile statistics of the latest neighbour build whose
 // read-back has arrived; it is never waited for.
 void poll_tile_stats(dsl_handle* h) {
-  if (!h->tstats_pending || hipEventQuery(h->ev_tstats) != hipSuccess) return;
-  h->tstats_pending = false;
-  h->share_short = (long long)h->host_tstats[5] * 12 > (long long)h->host_tstats[0];
+  if (!h->host_tstats) return;
+  const int seq = h->host_tstats[2];
+  if (seq == h->tstats_seen) return;
+  h->tstats_seen = seq;
+  h->share_short = (long long)h->host_tstats[1] * 12 > (long long)h->host_tstats[0];
 }
 
 int density_pass(dsl_handle* h) {
@@ -429,12 +429,13 @@ int density_pass(dsl_handle* h) {
   if (h->prm.math_mode == DSL_MATH_FAST) {
     poll_tile_stats(h);
     int rc = timed(h, DSL_K_DENSITY, [&] {
+      const int seq = ++h->tstats_seq;
       if (h->share_short)
         hipLaunchKernelGGL(k_density_tiled<true>, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap);
+                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq);
       else
         hipLaunchKernelGGL(k_density_tiled<false>, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap);
+                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq);
     });
     if (rc) return rc;
     h->dens_fresh = true;
@@ -663,8 +664,7 @@ void free_all(dsl_handle* h) {
       (void)hipEventDestroy(pr.second);
     }
   if (h->ev_band) (void)hipEventDestroy(h->ev_band);
-  if (h->ev_tstats) (void)hipEventDestroy(h->ev_tstats);
-  if (h->host_tstats) (void)hipHostFree(h->host_tstats);
+  if (h->host_tstats) (void)hipHostFree(const_cast<int*>(h->host_tstats));
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -801,11 +801,14 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
   if (h->prm.math_mode == DSL_MATH_FAST && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
   if (h->prm.math_mode == DSL_MATH_FAST) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_tstats), 8 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_tstats, hipEventDisableTiming) != hipSuccess) {
+    int* hp = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&hp), 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dev_tstats), hp, 0) != hipSuccess) {
       h->err = "tile statistics buffer";
       return bail(DSL_ERR_DEVICE);
     }
+    for (int k = 0; k < 8; ++k) hp[k] = 0;
+    h->host_tstats = hp;
   }
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;

@@ -324,10 +324,19 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
                                                           const int* __restrict__ n_tiles,
                                                           const int* __restrict__ cell_start, CSoa3 p,
                                                           float* __restrict__ rho, float* __restrict__ pterm,
-                                                          unsigned int* __restrict__ nmask, int mstride) {
+                                                          unsigned int* __restrict__ nmask, int mstride,
+                                                          volatile int* __restrict__ host_stats, int stats_seq) {
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+  // tile statistics of this neighbour build, written straight into host-mapped memory for the
+  // host to find whenever it next looks (it picks the kernel instantiations from them)
+  if (host_stats != nullptr && blockIdx.x == 0 && tid == 0) {
+    host_stats[0] = n_tiles[0];
+    host_stats[1] = n_tiles[5];
+    __threadfence_system();
+    host_stats[2] = stats_seq;
+  }
   TileWalk walk(*n_tiles);
   int item;
   while (walk.next(item)) {
