@@ -149,7 +149,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int* __restrict__ c
     carry += total;
   }
   for (int off = kWave / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, kWave));
-  if ((threadIdx.x & (kWave - 1)) == 0 && mx > 0) atomicMax(&stats->max_cell_count, mx);
+  // read first: almost every wave finds its maximum already recorded, and thousands of atomics on
+  // one address would serialise
+  if ((threadIdx.x & (kWave - 1)) == 0 && mx > 0 &&
+      mx > __hip_atomic_load(&stats->max_cell_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(&stats->max_cell_count, mx);
 }
 
 // ---------------------------------------------------------------------------------
