@@ -183,9 +183,11 @@ __device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& t
 
 // target index inside the tile -> interior row id (0..15), staged row, offset inside the row
 __device__ __forceinline__ void tile_target(const TileMeta& m, int t, int& srow, int& off) {
-  int ir = 0;
-#pragma unroll
-  for (int k = 1; k < kTB * kTB; ++k) ir += (t >= m.tprefix[k]) ? 1 : 0;
+  int ir = 0;  // largest interior row with tprefix[ir] <= t: binary search over the 16 rows
+  ir += (t >= m.tprefix[ir + 8]) ? 8 : 0;
+  ir += (t >= m.tprefix[ir + 4]) ? 4 : 0;
+  ir += (t >= m.tprefix[ir + 2]) ? 2 : 0;
+  ir += (t >= m.tprefix[ir + 1]) ? 1 : 0;
   srow = (ir / kTB + 1) * kTH + (ir % kTB + 1);
   off = m.cellS[srow * (kTH + 1) + 1] + (t - m.tprefix[ir]);
 }
