@@ -243,6 +243,13 @@ struct TileWalk {
 
 // q = clamp(a*b + c, 0, 1) in ONE instruction (VOP3 clamp output modifier).  The kernel
 // weights are q = 1 - r^2/h^2 or 1 - r/h, never above 1, so this is exactly max(q, 0).
+// the same with a wave-uniform factor (kept in an SGPR) and the constant 1: with three "v" operands
+// the compiler re-materialised the uniform factor into a VGPR in every iteration of the pair loop
+__device__ __forceinline__ float fma1_clamp01_uniform(float a, float b_uniform) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(d) : "v"(a), "s"(b_uniform));
+  return d;
+}
 __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
   float d;
   asm("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               r2 = fmaxf(r2, 1.0e-30f);  // the particle itself: keeps rsq finite, all terms stay 0
               const float rinv = __builtin_amdgcn_rsqf(r2);
               const float dist = r2 * rinv;
-              const float q = fma_clamp01(dist, ninvh, 1.0f);
+              const float q = fma1_clamp01_uniform(dist, ninvh);
               if constexpr (WANT_G) {
                 const float k = (q * q) * (pti + a.w) * rinv;
                 gx = __builtin_fmaf(dx, k, gx);
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               if constexpr (WANT_XS) {
                 // F(r)/A = (1 - r^2/h^2)^2 for both build-defined terms; the particle itself has d = 0
                 // and v_j = v_i, so it contributes nothing
-                const float q2 = fma_clamp01(r2, ninvhh, 1.0f);
+                const float q2 = fma1_clamp01_uniform(r2, ninvhh);
                 const float fw = q2 * q2;
                 cohx = __builtin_fmaf(dx, fw, cohx);
                 cohy = __builtin_fmaf(dyy, fw, cohy);
@@ -896,7 +903,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
               for (int u = 0; u < 4; ++u) {
                 const float4 cnd = A[j + u];
                 const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
-                const float q = fma_clamp01(r2, ninv, 1.0f);
+                const float q = fma1_clamp01_uniform(r2, ninv);
                 if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
                 else acc = __builtin_fmaf(q, q, acc);
               }
