@@ -630,7 +630,9 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // target's); bit (K-1-k) <-> candidate k of the run, K = run length rounded up to the
             // density sweep's unroll of 4.  A run without a mask (more than 32 candidates, or no masks
             // at all) is walked in chunks of 32 with every bit set.
-            auto walk_run = [&](int ri, int rr) {
+            // `first_word`: the run's first mask word, loaded by the caller one run ahead so that its
+            // global-memory latency passes under the previous run's walk
+            auto walk_run = [&](int ri, int rr, unsigned int first_word) {
               const int rb = m.row_lds[rr];
               int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
               const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
                 int top = j + clen - 1;
                 if (has_mask) {  // (then the run has at most 64 candidates: two words)
-                  mm = nmask[(size_t)word * mstride + g];
+                  mm = word == ri ? first_word : nmask[(size_t)word * mstride + g];
                   top = j + ((clen + 3) & ~3) - 1;
                   word = kMaskHigh + ri;
                 }
@@ -658,14 +660,21 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             };
             if constexpr (!SHARED) {
               int ri = 0;
+              unsigned int ahead = runs_masked != 0u ? nmask[g] : 0u;
 #pragma unroll 1
               for (int dz = -kTH; dz <= kTH; dz += kTH) {
 #pragma unroll 1
-                for (int dy = -1; dy <= 1; ++dy, ++ri) walk_run(ri, srow + dz + dy);
+                for (int dy = -1; dy <= 1; ++dy, ++ri) {
+                  const unsigned int word = ahead;
+                  if (ri < 8 && runs_masked != 0u) ahead = nmask[(size_t)(ri + 1) * mstride + g];
+                  walk_run(ri, srow + dz + dy, word);
+                }
               }
             } else {
 #pragma unroll 1
-              for (int ri = sub; ri < 9; ri += k) walk_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
+              for (int ri = sub; ri < 9; ri += k)
+                walk_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1),
+                         ((runs_masked >> ri) & 1u) ? nmask[(size_t)ri * mstride + g] : 0u);
             }
             DSL_STAMP(t5);
             DSL_STAMP_ADD(3, t4, t5);
