@@ -632,10 +632,14 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // at all) is walked in chunks of 32 with every bit set.
             // `first_word`: the run's first mask word, loaded by the caller one run ahead so that its
             // global-memory latency passes under the previous run's walk
-            auto walk_run = [&](int ri, int rr, unsigned int first_word) {
+            // (the run's LDS record range [j, je) likewise comes from the caller)
+            auto run_bounds = [&](int ri, int& j, int& je) {
+              const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
               const int rb = m.row_lds[rr];
-              int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-              const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+              j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
+              je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            };
+            auto walk_run = [&](int ri, int j, const int je, unsigned int first_word) {
               const bool has_mask = (runs_masked >> ri) & 1u;
               int word = ri;
               do {
@@ -659,22 +663,26 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               } while (j < je);
             };
             if constexpr (!SHARED) {
-              int ri = 0;
               unsigned int ahead = runs_masked != 0u ? nmask[g] : 0u;
+              int jn, jen;
+              run_bounds(0, jn, jen);
 #pragma unroll 1
-              for (int dz = -kTH; dz <= kTH; dz += kTH) {
-#pragma unroll 1
-                for (int dy = -1; dy <= 1; ++dy, ++ri) {
-                  const unsigned int word = ahead;
-                  if (ri < 8 && runs_masked != 0u) ahead = nmask[(size_t)(ri + 1) * mstride + g];
-                  walk_run(ri, srow + dz + dy, word);
+              for (int ri = 0; ri < 9; ++ri) {
+                const unsigned int word = ahead;
+                const int j = jn, je = jen;
+                if (ri < 8) {
+                  if (runs_masked != 0u) ahead = nmask[(size_t)(ri + 1) * mstride + g];
+                  run_bounds(ri + 1, jn, jen);
                 }
+                walk_run(ri, j, je, word);
               }
             } else {
 #pragma unroll 1
-              for (int ri = sub; ri < 9; ri += k)
-                walk_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1),
-                         ((runs_masked >> ri) & 1u) ? nmask[(size_t)ri * mstride + g] : 0u);
+              for (int ri = sub; ri < 9; ri += k) {
+                int j, je;
+                run_bounds(ri, j, je);
+                walk_run(ri, j, je, ((runs_masked >> ri) & 1u) ? nmask[(size_t)ri * mstride + g] : 0u);
+              }
             }
             DSL_STAMP(t5);
             DSL_STAMP_ADD(3, t4, t5);
