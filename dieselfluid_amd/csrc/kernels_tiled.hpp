@@ -560,13 +560,33 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
       float xsx = 0.f, xsy = 0.f, xsz = 0.f;  // XSPH sum / correction
       bool owned = false;
+      float pti_staged = 0.f;
       if (live) {
-        px = pin.x[g];
-        py = pin.y[g];
-        pz = pin.z[g];
-        vx = vin.x[g];
-        vy = vin.y[g];
-        vz = vin.z[g];
+        if (!nolds) {  // the target's own record is in the staged tile: no second trip to global memory
+          const int own = m.row_lds[srow] + off;
+          const float4 a = A[own];
+          px = a.x;
+          py = a.y;
+          pz = a.z;
+          pti_staged = a.w;
+          if constexpr (WANT_V || WANT_XS) {
+            const float4 b = B[own];
+            vx = b.x;
+            vy = b.y;
+            vz = b.z;
+          } else {
+            vx = vin.x[g];
+            vy = vin.y[g];
+            vz = vin.z[g];
+          }
+        } else {
+          px = pin.x[g];
+          py = pin.y[g];
+          pz = pin.z[g];
+          vx = vin.x[g];
+          vy = vin.y[g];
+          vz = vin.z[g];
+        }
         owned = !SLAB || OUT != kOutIntegrate || slab_owned(c, px, py, pz);
         if constexpr (SLAB && OUT == kOutIntegrate) {
           // split slab step: this launch integrates the band cell layers or the others, not both
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
         float cohx = 0.f, cohy = 0.f, cohz = 0.f;  // cohesion sum
         if (!nolds) {
           if constexpr (WANT_G || WANT_V || WANT_XS) {
-            const float pti = WANT_G ? pterm[g] : 0.f;
+            const float pti = WANT_G ? pti_staged : 0.f;
             const float ninvh = -c.inv_h;
             float lw_ = 0.f, xw_ = 0.f;
             const float ninvhh = -c.inv_hh;
@@ -663,7 +683,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               } while (j < je);
             };
             if constexpr (!SHARED) {
-              unsigned int ahead = runs_masked != 0u ? nmask[g] : 0u;
+              unsigned int ahead = nmask != nullptr ? nmask[g] : 0u;  // (not made to wait for runs_masked)
               int jn, jen;
               run_bounds(0, jn, jen);
 #pragma unroll 1
