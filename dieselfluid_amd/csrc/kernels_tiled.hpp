@@ -192,6 +192,14 @@ __device__ __forceinline__ void tile_target(const TileMeta& m, int t, int& srow,
   off = m.cellS[srow * (kTH + 1) + 1] + (t - m.tprefix[ir]);
 }
 
+// tile-local x cell (1..4) of the target at offset `off` of staged row `srow`: read off the row's
+// cell table, i.e. exactly the cell the sort put the particle in (no second evaluation of the
+// cell rule, no load of the position)
+__device__ __forceinline__ int tile_target_cell(const TileMeta& m, int srow, int off) {
+  const int* cs = &m.cellS[srow * (kTH + 1)];
+  return 1 + ((off >= cs[2]) ? 1 : 0) + ((off >= cs[3]) ? 1 : 0) + ((off >= cs[4]) ? 1 : 0);
+}
+
 // ds_read_b128 serves a wave in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and
 // the same +32 (MI355X_MICROARCH.md, LDS).  Lanes of one cell read the same record
 // (broadcast); cells two apart are 16 records = one full 256-byte bank row apart and would
@@ -376,7 +384,6 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     }
     __syncthreads();
     const int ntarg = m.tprefix[kTB * kTB];
-    const int x0 = (tile % tg.tnx) * kTB - 1;
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     // Targets are taken kTBlock at a time, one lane each.  A tile's LDS slot is held for as long as
     // its slowest pass, so a short pass -- the few targets beyond kTBlock once the lattice has
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
         const float4 me = A[m.row_lds[srow] + off];
         const float two_hh = 2.0f * c.inv_hh;
         const float sx = two_hh * me.x, sy = two_hh * me.y, sz = two_hh * me.z, a0 = 1.0f + me.w;
-        const int lx = cell_coord(p.x[g], c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+        const int lx = tile_target_cell(m, srow, off);
         // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
         auto sweep_run = [&](int ri, int rr) {
           const int rb = m.row_lds[rr];
@@ -544,7 +551,6 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     DSL_STAMP(t2);
     DSL_STAMP_ADD(1, t1, t2);
     const int ntarg = m.tprefix[kTB * kTB];
-    const int x0 = (tile % tg.tnx) * kTB - 1;
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     // short passes are shared out as in k_density_tiled: k lanes per target, each walking every
     // k-th run; after the butterfly the group's first lane finishes the target
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             const float ninvh = -c.inv_h;
             float lw_ = 0.f, xw_ = 0.f;
             const float ninvhh = -c.inv_hh;
-            const int lx = cell_coord(px, c.gmin[0], c.inv_cell, c.dims[0]) - x0;
+            const int lx = tile_target_cell(m, srow, off);
             // full per-pair arithmetic for candidate record j
             auto pair = [&](int j) {
               const float4 a = A[j];
