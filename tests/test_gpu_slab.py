@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 STEPS = 10
 
 
-def _worker(rank, world, port, math_mode, n3, overlap, vscale, out):
+def _worker(rank, world, port, math_mode, n3, overlap, vscale, out, axis=2):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -28,8 +28,8 @@ def _worker(rank, world, port, math_mode, n3, overlap, vscale, out):
     torch.cuda.set_device(0)
     from dieselfluid_amd.slab import SlabDriver
     SlabDriver.REPLAN_EVERY = 4  # exercise the message re-sizing inside the run
-    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=2, overlap=overlap,
-                              vel_fn=lambda ids, pos: vscale * _vel_fn(ids, pos, axis=2))
+    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=axis, overlap=overlap,
+                              vel_fn=lambda ids, pos: vscale * _vel_fn(ids, pos, axis=axis))
     assert drv.overlap == (overlap if overlap is not None else math_mode == 1)
     caps0 = (drv.engine.cap_full, drv.engine.cap_x)
     drv.wcsph_step(STEPS)
@@ -43,7 +43,7 @@ def _worker(rank, world, port, math_mode, n3, overlap, vscale, out):
     dist.destroy_process_group()
 
 
-def _single(n3, math_mode, vscale, steps=STEPS, shuffle=False):
+def _single(n3, math_mode, vscale, steps=STEPS, shuffle=False, axis=2):
     """single-engine run; `shuffle` also re-orders the particles and moves the grid origin (other
     cells, other tiles, other tile-relative roundings in FAST mode): what a slab rank's own grid does"""
     from dieselfluid_amd import SPHEngine, scenes
@@ -51,7 +51,7 @@ def _single(n3, math_mode, vscale, steps=STEPS, shuffle=False):
     if shuffle:
         for a in range(3):
             p.grid_min[a] -= 0.37 * p.h
-    vel = vscale * _vel_fn(np.arange(n3 ** 3), pos, 2)
+    vel = vscale * _vel_fn(np.arange(n3 ** 3), pos, axis)
     perm = np.random.default_rng(0).permutation(n3 ** 3) if shuffle else np.arange(n3 ** 3)
     eng = SPHEngine(p)
     eng.upload("positions", pos[perm])
@@ -94,6 +94,25 @@ def test_hip_slabs_match_single_engine(tmp_path, math_mode, overlap, world, n3):
     print(f"slab-vs-single x {ex:.2e} (tol {tol_x:.2e})  v {ev:.2e} (tol {tol_v:.2e})")
     assert ex < tol_x
     assert ev < tol_v
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_hip_slabs_along_x_and_y(tmp_path, axis):
+    """the slab axis is a parameter: rows run along x, so x slabs cut through rows and y slabs between them"""
+    n3, world, math_mode = 32, 2, 1
+    out = str(tmp_path / "slab_gpu.npz")
+    mp.spawn(_worker, args=(world, _free_port(), math_mode, n3, True, 1.0, out, axis), nprocs=world, join=True)
+    z = np.load(out)
+    info = z["info"]
+    assert np.all(z["seen"] == 1)
+    assert info[:, 1].sum() == n3 ** 3
+    assert np.all(info[:, 2] == 0) and np.all(info[:, 3] == 0)
+    pos, vel = _single(n3, math_mode, 1.0, axis=axis)
+    pos_s, vel_s = _single(n3, math_mode, 1.0, shuffle=True, axis=axis)
+    tol_x = max(4e-6, 5.0 * helpers.rel_err(pos_s, pos))
+    tol_v = max(1e-4, 5.0 * helpers.rel_err(vel_s, vel))
+    assert helpers.rel_err(z["pos"], pos) < tol_x
+    assert helpers.rel_err(z["vel"], vel) < tol_v
 
 
 def test_split_step_flags_a_margin_violation(tmp_path):
