@@ -7,7 +7,7 @@
 //   forces         2 x 3 arrays  only materialised while they differ from force_reset
 //   pci pos/vel    2 x 6 arrays  PCISPH predictor state (pcisph_darwin.go:28-41)
 //   rho, pterm, press            per-slot density, P/rho^2, "pressures" buffer
-//   cellid, rank, cell_count, cell_start, block_sums   neighbour table
+//   rank, cell_count, cell_start, block_sums   neighbour table
 // Host buffers are the reference's interleaved xyz float32 (model/particle_array.go:5-15).
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see
@@ -75,7 +75,7 @@ struct dsl_handle {
   float* xsph[3] = {};   // build-defined XSPH correction of the current step (PCISPH path)
   unsigned int* nmask = nullptr;  // FAST: per-particle in-range masks from the density sweep (kMaskWords x cap)
   bool masks_valid = false;
-  int *cellid = nullptr, *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
+  int *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
   float* stage = nullptr;
   DevStats* dstats = nullptr;
   int cur_pv = 0, cur_ids = 0, cur_f = 0, cur_pci = 0;
@@ -309,8 +309,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   CSoa3 p = cpos(h);
   HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
-    hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z, h->cellid,
-                       h->rank, h->cell_count);
+    hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z, h->rank,
+                       h->cell_count);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
@@ -343,8 +343,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   a.ids_src = h->ids[h->cur_ids];
   a.ids_dst = h->ids[h->cur_ids ^ 1];
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, h->cellid, h->rank,
-                       h->cell_start);
+    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, p, h->rank, h->cell_start);
   });
   if (rc) return rc;
   if (carry_derived) {
@@ -358,8 +357,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
       b.nf = 1;
       b.ids_src = h->ids[h->cur_ids];      // ids re-scattered identically; harmless
       b.ids_dst = h->ids[h->cur_ids ^ 1];
-      hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, b, h->cellid, h->rank,
-                         h->cell_start);
+      hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, b, p, h->rank, h->cell_start);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipMemcpyAsync(arr, h->scratch1, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -639,7 +637,6 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->pterm);
   (void)hipFree(h->press);
   (void)hipFree(h->scratch1);
-  (void)hipFree(h->cellid);
   (void)hipFree(h->rank);
   (void)hipFree(h->cell_count);
   (void)hipFree(h->cell_start);
@@ -772,7 +769,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     if ((rc = dev_alloc(h, &h->ids[w], n))) return bail(rc);
   }
   if ((rc = dev_alloc(h, &h->rho, n)) || (rc = dev_alloc(h, &h->pterm, n)) || (rc = dev_alloc(h, &h->press, n)) ||
-      (rc = dev_alloc(h, &h->scratch1, n)) || (rc = dev_alloc(h, &h->cellid, n)) || (rc = dev_alloc(h, &h->rank, n)) ||
+      (rc = dev_alloc(h, &h->scratch1, n)) || (rc = dev_alloc(h, &h->rank, n)) ||
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||

@@ -1,5 +1,5 @@
 // kernels_grid.hpp -- uniform-grid neighbour table built by a GPU counting sort:
-//   k_cell_rank  : cell hash + wave-aggregated histogram (segmented by __ballot)
+//   k_cell_rank  : cell hash + wave-aggregated histogram (segmented by __ballot); rank inside the cell
 //   k_scan_*     : exclusive prefix sum of the cell histogram, wavefront scan
 //                  (__shfl_up) staged through LDS, three phases
 //   k_scatter    : counting-sort scatter of the SoA particle arrays
@@ -24,22 +24,21 @@ constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lan
 // particles only (cell_start[ncell] = their number).  A particle that has just crossed the
 // slab plane stays finite: it serves as a ghost for one more step, because the neighbour
 // packed its own band before receiving it.
+// the cell of a particle for the sort: cell_of, or the pseudo cell `ncell` for a stale ghost
+__device__ __forceinline__ int sort_cell(const DevConsts& c, float x, float y, float z) {
+  if (c.slab_axis >= 0 && !((x == x) && (y == y) && (z == z))) return c.ncell;
+  return cell_of(c, x, y, z);
+}
+
 __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* __restrict__ px,
                                                       const float* __restrict__ py,
-                                                      const float* __restrict__ pz, int* __restrict__ cellid,
-                                                      int* __restrict__ rank, int* __restrict__ cell_count) {
+                                                      const float* __restrict__ pz, int* __restrict__ rank,
+                                                      int* __restrict__ cell_count) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
   int cell = -1;
   const int n = live_n(c);
-  if (i < n) {
-    const float x = px[i], y = py[i], z = pz[i];
-    cell = cell_of(c, x, y, z);
-    if (c.slab_axis >= 0) {
-      const bool finite = (x == x) && (y == y) && (z == z);
-      if (!finite) cell = c.ncell;
-    }
-  }
+  if (i < n) cell = sort_cell(c, px[i], py[i], pz[i]);
   const int prev = __shfl_up(cell, 1, kWave);
   const bool head = (lane == 0) || (cell != prev);
   const unsigned long long heads = __ballot(head);
@@ -52,10 +51,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   // (a whole band of stale ghosts would otherwise hammer one counter: same-address atomics serialise)
   if (lane == head_lane && cell >= 0 && cell != c.ncell) base = atomicAdd(&cell_count[cell], run);
   base = __shfl(base, head_lane, kWave);
-  if (i < n) {
-    cellid[i] = cell;
-    rank[i] = base + (lane - head_lane);
-  }
+  if (i < n) rank[i] = base + (lane - head_lane);  // (the scatter recomputes the cell: cheaper than 8 B of traffic)
 }
 
 // ---------------------------------------------------------------------------------
@@ -169,13 +165,15 @@ struct ScatterArrays {
   int* ids_dst;
 };
 
-__global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, const int* __restrict__ cellid,
+// `pos`: the unsorted positions the ranks were computed from
+__global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, CSoa3 pos,
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
-  if (cellid[i] == c.ncell) return;  // stale ghost: dropped
-  const int d = cell_start[cellid[i]] + rank[i];
+  const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+  if (cell == c.ncell) return;  // stale ghost: dropped
+  const int d = cell_start[cell] + rank[i];
   a.ids_dst[d] = a.ids_src[i];
   for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
 }
