@@ -4,12 +4,13 @@ The reference has no multi-process path; this is the buil
 host logic above the C ABI (dsl_slab_* in include/dslsph.h).  torch.distributed is the
 transport only (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU tests).
 
-Per step and per neighbour ONE message: every owned particle within 2h of the slab plane
-(migrants that crossed the plane included), 28 bytes each (x, v, global id).  The
-receiver keeps those inside its own [lo,hi) as newly owned and the rest as ghosts.  A 2h
-band lets the receiver recompute the ghosts' densities itself, so the force pass needs no
-second exchange: ghosts within h of the plane see their full neighbourhood, and only
-those contribute to owned particles.
+Per step and per neighbour ONE message: every owned particle within 2h of the slab plane.
+Those within h (and the migrants beyond the plane) travel as full records (x, v, global id:
+28 bytes; 52 with the PCISPH predictor state), the outer half of the band as positions only
+(12 bytes).  The receiver keeps full records inside its own [lo,hi) as newly owned and the
+rest as ghosts.  A 2h band lets the receiver recompute the ghosts' densities itself, so the
+force pass needs no second exchange: ghosts within h of the plane see their full
+neighbourhood, and only those contribute to owned particles.
 
 The driver is engine-agnostic: anything implementing pack/append/nn/density_all/
 force_pass (HipSlabEngine here; an oracle-backed stand-in lives in tests/) can be driven,
@@ -231,7 +232,7 @@ class SlabDriver:
             elif self.overlap:
                 e.force_band()       # owned particles of the cell layers near the planes
                 send = e.pack_band(self.width_full, lo_nb is not None, hi_nb is not None)
-                e.comm_stream.wait_stream(torch.cuda.current_stream())  # ... the pack, not what follows
+                e.comm_stream.wait_stream(torch.cuda.current_stream(e.dev))  # ... the pack, not what follows
                 with torch.cuda.stream(e.comm_stream):
                     posted = self._post(send)
                 e.force_inner()      # the rest, concurrently with the transfer
