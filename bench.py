@@ -137,6 +137,9 @@ def main():
                 p.st_kappa = 25.0 * p.h * p.h
 
         pci = args.method == "pcisph"
+        # engine kernels, RCCL calls and torch's own small ops are ordered through torch's current
+        # stream: give it a stream of its own instead of the legacy default stream
+        torch.cuda.set_stream(torch.cuda.Stream(torch.device("cuda", local_rank)))
         drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank, pcisph=pci,
                                        params_hook=pci_params if pci else None,
                                        overlap=False if args.no_overlap else None)
