@@ -821,7 +821,8 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   }
   hipLaunchKernelGGL(k_iota, dim3(grid_for(h->cap)), dim3(kBlock), 0, h->stream, h->cap, h->ids[0]);
   DevStats init{};
-  init.max_vel_bits = params->max_vel > 0.f ? *reinterpret_cast<const unsigned int*>(&params->max_vel) : 0u;
+  // (params->max_vel, the reference's initial maxVel, is folded in by dsl_get_stats: the device
+  // counters hold squared magnitudes)
   if (hipMemcpyAsync(h->dstats, &init, sizeof(init), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess) {
     h->err = "device initialisation failed";
@@ -1677,8 +1678,12 @@ int dsl_get_stats(dsl_handle* h, dsl_stats* out) {
   DevStats d{};
   HIP_TRY(h, hipMemcpyAsync(&d, h->dstats, sizeof(d), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  std::memcpy(&out->max_vel, &d.max_vel_bits, 4);
-  std::memcpy(&out->max_f, &d.max_f_bits, 4);
+  float v2 = 0.f, f2 = 0.f;
+  std::memcpy(&v2, &d.max_vel_bits, 4);
+  std::memcpy(&f2, &d.max_f_bits, 4);
+  out->max_vel = std::sqrt(v2);  // float overload: correctly rounded, as the per-particle square root was
+  out->max_f = std::sqrt(f2);
+  if (h->prm.max_vel > out->max_vel) out->max_vel = h->prm.max_vel;  // maxVel starts at the parameter (fluid.go:25)
   std::memcpy(&out->pci_max_error, &d.pci_last_err_bits, 4);
   out->pci_iters = d.pci_iters;
   out->steps = h->steps;

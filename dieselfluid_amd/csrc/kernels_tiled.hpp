@@ -568,8 +568,11 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       bool owned = false;
       float pti_staged = 0.f;
       if (live) {
-        if (!nolds) {  // the target's own record is in the staged tile: no second trip to global memory
-          const int own = m.row_lds[srow] + off;
+        // the target's own record is in the staged tile: no second trip to global memory (the reads
+        // are unconditional and the rare unstaged tile overrides them, so that the compiler keeps
+        // LDS and global loads apart instead of merging them into flat loads)
+        {
+          const int own = nolds ? 0 : m.row_lds[srow] + off;
           const float4 a = A[own];
           px = a.x;
           py = a.y;
@@ -580,15 +583,14 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             vx = b.x;
             vy = b.y;
             vz = b.z;
-          } else {
-            vx = vin.x[g];
-            vy = vin.y[g];
-            vz = vin.z[g];
           }
-        } else {
+        }
+        if (nolds) {
           px = pin.x[g];
           py = pin.y[g];
           pz = pin.z[g];
+        }
+        if (nolds || !(WANT_V || WANT_XS)) {
           vx = vin.x[g];
           vy = vin.y[g];
           vz = vin.z[g];

@@ -62,8 +62,8 @@ __device__ __forceinline__ int live_n(const DevConsts& c) { return c.n_ptr ? *c.
 
 // Host-visible counters living in device memory (fluid.go:25-26, pcisph_darwin.go:46-98).
 struct DevStats {
-  unsigned int max_vel_bits;  // non-negative float bit patterns order like unsigned ints
-  unsigned int max_f_bits;
+  unsigned int max_vel_bits;  // max |v|^2 (non-negative float bit patterns order like unsigned ints)
+  unsigned int max_f_bits;    // max |F|^2
   unsigned int pci_cur_err_bits;   // running max of the current PCISPH iteration
   unsigned int pci_last_err_bits;  // max_error_ratio of the last completed iteration
   int pci_iters;
