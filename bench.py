@@ -151,26 +151,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Per-kernel HIP events bracket every launch: free at N=1 (7 launches per 2.7 ms step), about
-    # 10 % of a slab rank's step (16 launches per 0.5 ms).  For N>1 they are therefore recorded
-    # in a short segment AFTER the timed region; `value` is measured without them.
+    # Per-kernel HIP events bracket launches: around every kernel they cost 1.8 % of the 2.5 ms step
+    # at N=1 and about 10 % of a slab rank's 0.5 ms step.  N=1 therefore times only the two dominant
+    # kernels (the roofline's) inside the timed region and the rest in a short segment after it;
+    # N>1 times everything in that segment, `value` is measured without any.
     events_in_region = world == 1
     step(args.warmup)
     for e in engines:
         e.timing_reset()
-        e.timing_enable(events_in_region)
+        e.timing_enable(2 if events_in_region else 0)
     barrier()
     t0 = time.perf_counter()
     step(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    timed_launch_steps = args.steps
-    if not events_in_region:
-        timed_launch_steps = min(args.steps, 10)
-        for e in engines:
-            e.timing_enable(True)
-        step(timed_launch_steps)
-        barrier()
+    hot = {k: engines[0].timing(k) for k in ("density", "force_integrate", "pci_density")}
+    timed_launch_steps = min(args.steps, 10)
+    for e in engines:
+        e.timing_reset()
+        e.timing_enable(True)
+    step(timed_launch_steps)
+    barrier()
     for e in engines:
         e.timing_enable(False)
     if world > 1:
@@ -187,13 +188,17 @@ def main():
                           device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ov, op=dist.ReduceOp.MAX)
         overflow, band_missed = int(ov[0].item()), int(ov[1].item())
-    ms_d, n_d = eng.timing("density")
-    ms_f, n_f = eng.timing("force_integrate")
-    if n_f > timed_launch_steps:  # split force pass: two launches per step, quote the pass
-        ms_f = ms_f * n_f / timed_launch_steps
+    def timing_of(k):  # N=1: the dominant kernels as timed inside the timed region
+        return hot[k] if events_in_region and k in hot else eng.timing(k)
+
+    ms_d, n_d = timing_of("density")
+    ms_f, n_f = timing_of("force_integrate")
+    steps_f = args.steps if events_in_region else timed_launch_steps
+    if n_f > steps_f:  # split force pass: two launches per step, quote the pass
+        ms_f = ms_f * n_f / steps_f
     n_local = eng.n
     if args.method == "pcisph":
-        ms_f = eng.timing("pci_density")[0]  # dominant PCISPH kernel: predicted density, 20 B/particle
+        ms_f = timing_of("pci_density")[0]  # dominant PCISPH kernel: predicted density, 20 B/particle
         kname, kms, kbytes = "k_pci_density", ms_f, 20
     elif ms_f >= ms_d:
         kname, kms, kbytes = "k_force_integrate", ms_f, BYTES_FORCE
@@ -251,7 +256,7 @@ def main():
                 "pass_frac_68B": round(n_local * 68 / ((ms_d + ms_f) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if (ms_d + ms_f) > 0 else None,
             },
-            "kernels_ms": {k: round(eng.timing(k)[0], 4) for k in
+            "kernels_ms": {k: round(timing_of(k)[0], 4) for k in
                            (("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")
                             if args.method == "wcsph" else
                             ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
@@ -259,7 +264,8 @@ def main():
             "slab_overflow": overflow,
             "slab_band_missed": band_missed,
             "slab_overlap": bool(world > 1 and drv.overlap),
-            "kernel_events": "in the timed region" if events_in_region else
+            "kernel_events": ("density / force kernels in the timed region, the others in a "
+                              f"{timed_launch_steps}-step segment after it") if events_in_region else
                              f"separate {timed_launch_steps}-step segment after the timed region",
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,

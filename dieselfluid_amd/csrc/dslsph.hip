@@ -83,7 +83,7 @@ struct dsl_handle {
   int64_t steps = 0;
   std::string err;
   // timing
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 every kernel, 2 the step's dominant kernels only
   std::vector<hipEvent_t> pool;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[DSL_K_COUNT];
   double total_ms[DSL_K_COUNT] = {};
@@ -217,7 +217,7 @@ hipEvent_t get_event(dsl_handle* h) {
 
 template <class F>
 int timed(dsl_handle* h, int kid, F&& launch) {
-  if (h->timing) {
+  if (h->timing == 1 || (h->timing == 2 && (kid == DSL_K_DENSITY || kid == DSL_K_FORCE_INTEGRATE || kid == DSL_K_PCI_DENSITY))) {
     hipEvent_t a = get_event(h), b = get_event(h);
     (void)hipEventRecord(a, h->stream);
     launch();
@@ -1701,7 +1701,7 @@ int dsl_sync(dsl_handle* h) {
 
 int dsl_timing_enable(dsl_handle* h, int on) {
   CHECK_HANDLE(h);
-  h->timing = on != 0;
+  h->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
   return DSL_OK;
 }
 int dsl_timing_reset(dsl_handle* h) {

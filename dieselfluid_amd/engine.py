@@ -275,7 +275,8 @@ class SPHEngine:
         return s
 
     # -- timing ---------------------------------------------------------------------
-    def timing_enable(self, on: bool = True):
+    def timing_enable(self, on=True):
+        """True / 1: every kernel; 2: only the step's dominant kernels; False / 0: off"""
         self._ck(self._L.dsl_timing_enable(self._h, int(on)))
 
     def timing_reset(self):

@@ -235,7 +235,9 @@ int dsl_sync(dsl_handle *h); /* Queue.Finish() pcisph_gpu_darwin.go:261,271 */
 int dsl_set_stream(dsl_handle *h, void *hip_stream);
 int dsl_use_own_stream(dsl_handle *h);
 
-/* Per-kernel device timing with HIP events recorded on the launch stream. */
+/* Per-kernel device timing with HIP events recorded on the launch stream.  on = 1: every kernel
+ * (1.8 % of a 2.5 ms step at 16M particles, ~10 % of a 0.5 ms slab step); on = 2: only the
+ * dominant kernels of a step (DSL_K_DENSITY, DSL_K_FORCE_INTEGRATE, DSL_K_PCI_DENSITY); 0: off. */
 int dsl_timing_enable(dsl_handle *h, int on);
 int dsl_timing_reset(dsl_handle *h);
 int dsl_timing_get(dsl_handle *h, int kernel_id, double *avg_ms, int64_t *launches);
