@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--no-timing", action="store_true")
     ap.add_argument("--null-stream", action="store_true", help="run on torch's default (null) stream")
     ap.add_argument("--no-replan", action="store_true", help="no message re-sizing (and so no host sync) in the timed loop")
+    ap.add_argument("--dump", default="", help="write the owned state (sorted by id) to this .npz after the run")
     ap.add_argument("--nccl", action="store_true", help="send the bands through RCCL (to this same rank)")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -119,6 +120,11 @@ def main():
                                    ("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")},
            "ideal_ms_at_1gpu_rate": None}
     print(json.dumps(out))
+    if a.dump:
+        import numpy as np
+        ids, pos, vel = drv.engine.owned_state(drv.axis, drv.lo, drv.hi)
+        o = np.argsort(ids)
+        np.savez(a.dump, ids=ids[o], pos=pos[o], vel=vel[o])
     dist.destroy_process_group()
 
 
