@@ -691,16 +691,26 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               } while (j < je);
             };
             if constexpr (!SHARED) {
-              unsigned int ahead = nmask != nullptr ? nmask[g] : 0u;  // (not made to wait for runs_masked)
+              // The wave spends, on every run, as many iterations as its busiest lane has neighbours
+              // there -- and which runs are busy depends on where in its cell a particle sits (near the
+              // +y face: the dy = +1 rows).  Each lane therefore visits the 9 runs in an order mirrored
+              // by its own half-cell in y and z, so that at every step all lanes are on a run of similar
+              // weight ("towards my corner" first).  Sums are order-independent up to rounding.
+              const float fy = (py - c.gmin[1]) * c.inv_cell, fz = (pz - c.gmin[2]) * c.inv_cell;
+              const int sy = (fy - floorf(fy)) >= 0.5f ? 1 : -1, sz = (fz - floorf(fz)) >= 0.5f ? 1 : -1;
+              auto run_of = [&](int s) { return ((s / 3 - 1) * sz + 1) * 3 + ((s % 3 - 1) * sy + 1); };
+              int rn = run_of(0);
+              unsigned int ahead = nmask != nullptr ? nmask[(size_t)rn * mstride + g] : 0u;  // (not behind runs_masked)
               int jn, jen;
-              run_bounds(0, jn, jen);
+              run_bounds(rn, jn, jen);
 #pragma unroll 1
-              for (int ri = 0; ri < 9; ++ri) {
+              for (int s = 0; s < 9; ++s) {
                 const unsigned int word = ahead;
-                const int j = jn, je = jen;
-                if (ri < 8) {
-                  if (runs_masked != 0u) ahead = nmask[(size_t)(ri + 1) * mstride + g];
-                  run_bounds(ri + 1, jn, jen);
+                const int j = jn, je = jen, ri = rn;
+                if (s < 8) {
+                  rn = run_of(s + 1);
+                  if (runs_masked != 0u) ahead = nmask[(size_t)rn * mstride + g];
+                  run_bounds(rn, jn, jen);
                 }
                 walk_run(ri, j, je, word);
               }
