@@ -408,18 +408,26 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
           const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
           if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
           unsigned int mask = 0u;
-          auto sweep_to = [&](int jend) {
-            for (; j < jend; j += 4) {
+          // q = clamp(1 - r^2/h^2), r^2 = |xi|^2 + |xj|^2 - 2 xi.xj, with everything but the three
+          // products folded into the staged w_j = -|xj|^2/h^2 and the per-target constants
+          auto test4 = [&](int jj) {
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float4 cnd = A[j + u];
-                // q = clamp(1 - r^2/h^2), r^2 = |xi|^2 + |xj|^2 - 2 xi.xj, with everything but the
-                // three products folded into the staged w_j = -|xj|^2/h^2 and the per-target constants
-                const float q = fma_clamp01(cnd.z, sz, __builtin_fmaf(cnd.y, sy, __builtin_fmaf(cnd.x, sx, cnd.w + a0)));
-                mask_push(mask, q);
-                if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
-                else acc = __builtin_fmaf(q, q, acc);
-              }
+            for (int u = 0; u < 4; ++u) {
+              const float4 cnd = A[jj + u];
+              const float q = fma_clamp01(cnd.z, sz, __builtin_fmaf(cnd.y, sy, __builtin_fmaf(cnd.x, sx, cnd.w + a0)));
+              mask_push(mask, q);
+              if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+              else acc = __builtin_fmaf(q, q, acc);
+            }
+          };
+          auto sweep_to = [&](int jend) {  // 8 candidates per trip while they last, then at most one block of 4
+            for (; j + 4 < jend; j += 8) {
+              test4(j);
+              test4(j + 4);
+            }
+            if (j < jend) {
+              test4(j);
+              j += 4;
             }
           };
           const int j32 = j + 32;
