@@ -919,10 +919,10 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       for (int r = wid; r < kTRows; r += kTBlock / kWave) {
         const int gs = m.row_gs[r], len = m.row_len[r], ls = m.row_lds[r];
         for (int i = lane; i < len + kTPad; i += kWave) {
-          float4 v = make_float4(kFar, kFar, kFar, 3.0f * kFar * kFar);
-          if (i < len) {
+          float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+          if (i < len) {  // records as in k_density_tiled: tile-relative x, y, z and w = -|x|^2/h^2
             const float x = p.x[gs + i] - ox, y = p.y[gs + i] - oy, z = p.z[gs + i] - oz;
-            v = make_float4(x, y, z, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+            v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
           }
           A[ls + i] = v;
         }
@@ -948,11 +948,21 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       float density;
       if (!ovf && inside) {
         const float rx = qx - ox, ry = qy - oy, rz = qz - oz;
-        const float m2x = -2.0f * rx, m2y = -2.0f * ry, m2z = -2.0f * rz;
-        const float ni = __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
-        const float ninv = -c.inv_hh;
+        const float two_hh = 2.0f * c.inv_hh;
+        const float sx = two_hh * rx, sy = two_hh * ry, sz = two_hh * rz;
+        const float a0 = 1.0f - c.inv_hh * __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
         float acc = 0.f, acc1 = 0.f;
         const int qrow = lz * kTH + ly;
+        // q = clamp(1 - r^2/h^2) = clamp(a0 + w_j + (2/h^2) q.x_j), as in k_density_tiled
+        auto test4 = [&](int jj) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4 cnd = A[jj + u];
+            const float q = fma_clamp01(cnd.z, sz, __builtin_fmaf(cnd.y, sy, __builtin_fmaf(cnd.x, sx, cnd.w + a0)));
+            if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+            else acc = __builtin_fmaf(q, q, acc);
+          }
+        };
 #pragma unroll 1
         for (int dz = -kTH; dz <= kTH; dz += kTH) {
 #pragma unroll 1
@@ -961,16 +971,11 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
             const int rb = m.row_lds[rr];
             int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
             const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-            for (; j < je; j += 4) {
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float4 cnd = A[j + u];
-                const float r2 = __builtin_fmaf(cnd.z, m2z, __builtin_fmaf(cnd.y, m2y, __builtin_fmaf(cnd.x, m2x, cnd.w + ni)));
-                const float q = fma1_clamp01_uniform(r2, ninv);
-                if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
-                else acc = __builtin_fmaf(q, q, acc);
-              }
+            for (; j + 4 < je; j += 8) {
+              test4(j);
+              test4(j + 4);
             }
+            if (j < je) test4(j);
           }
         }
         density = __builtin_fmaf(acc + acc1, c.mass * c.A, c.W0);  // starts at W0, self included
