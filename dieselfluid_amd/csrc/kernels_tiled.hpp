@@ -124,40 +124,40 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
 // ---------------------------------------------------------------------------------
 // tile set-up shared by both kernels: row table, LDS offsets, target prefix
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& tg, int tile,
-                                           const int* __restrict__ cell_start, TileMeta& m) {
+// The set-up in two halves, so that a kernel can have the NEXT tile's loads in flight while it
+// sweeps the current one: tile_setup_load issues the global loads of one staged row per lane
+// (lanes < kTRows) into registers, tile_setup_commit turns them into the row table (two barriers).
+struct TileSetupRegs {
+  int s[kTH + 1];  // cell_start of the row's 6 cells and the end; all 0 for a row outside the grid
+};
+__device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGrid& tg, int tile,
+                                                const int* __restrict__ cell_start, TileSetupRegs& r) {
   const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k <= kTH; ++k) r.s[k] = 0;
+  if (tid >= kTRows) return;
   const int tx = tile % tg.tnx, ty = (tile / tg.tnx) % tg.tny, tz = tile / (tg.tnx * tg.tny);
   const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
-  if (tid < kTRows) {
-    const int ry = tid % kTH, rz = tid / kTH;
-    const int y = ty * kTB - 1 + ry, z = tz * kTB - 1 + rz;
-    int len = 0, gs = 0;
-    int offs[kTH + 1];
+  const int ry = tid % kTH, rz = tid / kTH;
+  const int y = ty * kTB - 1 + ry, z = tz * kTB - 1 + rz;
+  if (y >= 0 && y < ny && z >= 0 && z < nz) {
+    const int row = (z * ny + y) * nx;
+    // cells tx*4-1 .. tx*4+4, clamped to the grid: out-of-grid cells are empty
 #pragma unroll
-    for (int k = 0; k <= kTH; ++k) offs[k] = 0;
-    if (y >= 0 && y < ny && z >= 0 && z < nz) {
-      const int row = (z * ny + y) * nx;
-      // cells tx*4-1 .. tx*4+4, clamped to the grid: out-of-grid cells are empty
-      int prev = -1;
-#pragma unroll
-      for (int k = 0; k <= kTH; ++k) {
-        int x = tx * kTB - 1 + k;
-        x = x < 0 ? 0 : (x > nx ? nx : x);
-        const int s = cell_start[row + x];
-        if (k == 0) {
-          gs = s;
-          prev = s;
-        }
-        offs[k] = s - gs;
-        (void)prev;
-      }
-      len = offs[kTH];
+    for (int k = 0; k <= kTH; ++k) {
+      int x = tx * kTB - 1 + k;
+      x = x < 0 ? 0 : (x > nx ? nx : x);
+      r.s[k] = cell_start[row + x];
     }
-    m.row_gs[tid] = gs;
-    m.row_len[tid] = len;
+  }
+}
+__device__ __forceinline__ void tile_setup_commit(const TileSetupRegs& r, TileMeta& m) {
+  const int tid = threadIdx.x;
+  if (tid < kTRows) {
+    m.row_gs[tid] = r.s[0];
+    m.row_len[tid] = r.s[kTH] - r.s[0];
 #pragma unroll
-    for (int k = 0; k <= kTH; ++k) m.cellS[tid * (kTH + 1) + k] = offs[k];
+    for (int k = 0; k <= kTH; ++k) m.cellS[tid * (kTH + 1) + k] = r.s[k] - r.s[0];
   }
   __syncthreads();
   if (tid < kWave) {  // wave 0: exclusive prefix of (len + pad) over the 36 rows
@@ -171,14 +171,20 @@ __device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& t
     // targets: interior rows (ry,rz in 1..4), interior cells 1..4
     int tv = 0;
     if (tid < kTB * kTB) {
-      const int r = (tid / kTB + 1) * kTH + (tid % kTB + 1);
-      tv = m.cellS[r * (kTH + 1) + kTB + 1] - m.cellS[r * (kTH + 1) + 1];
+      const int rr = (tid / kTB + 1) * kTH + (tid % kTB + 1);
+      tv = m.cellS[rr * (kTH + 1) + kTB + 1] - m.cellS[rr * (kTH + 1) + 1];
     }
     const int tinc = wave_inclusive_scan(tv);
     if (tid < kTB * kTB) m.tprefix[tid] = tinc - tv;
     if (tid == kTB * kTB - 1) m.tprefix[kTB * kTB] = tinc;
   }
   __syncthreads();
+}
+__device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& tg, int tile,
+                                           const int* __restrict__ cell_start, TileMeta& m) {
+  TileSetupRegs r;
+  tile_setup_load(c, tg, tile, cell_start, r);
+  tile_setup_commit(r, m);
 }
 
 // target index inside the tile -> interior row id (0..15), staged row, offset inside the row
@@ -356,15 +362,23 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
   }
   TileWalk walk(*n_tiles);
   int item;
-  while (walk.next(item)) {
-    const int tile = tiles[item];
+  bool have = walk.next(item);
+  TileSetupRegs next_rows;  // the NEXT tile's row loads travel under the current tile's sweep
+  int tile = 0;
+  if (have) {
+    tile = tiles[item];
+    tile_setup_load(c, tg, tile, cell_start, next_rows);
+  }
+  while (have) {
     __syncthreads();  // previous tile's LDS is no longer read
-    tile_setup(c, tg, tile, cell_start, m);
+    tile_setup_commit(next_rows, m);
+    const int cur_tile = tile;
+    have = walk.next(item);
     const bool ovf = m.overflow != 0;
     // tile centre in world coordinates
-    const float ox = c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
-    const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
-    const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
+    const float ox = c.gmin[0] + ((cur_tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
+    const float oy = c.gmin[1] + (((cur_tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
+    const float oz = c.gmin[2] + ((cur_tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
       stage_rows<3>(
           m, wid, lane,
@@ -383,6 +397,10 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
           });
     }
     __syncthreads();
+    if (have) {
+      tile = tiles[item];
+      tile_setup_load(c, tg, tile, cell_start, next_rows);
+    }
     const int ntarg = m.tprefix[kTB * kTB];
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     // Targets are taken kTBlock at a time, one lane each.  A tile's LDS slot is held for as long as
@@ -519,11 +537,14 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
   const int* __restrict__ list = ghost_tile ? ghost_tiles : tiles;
   TileWalk walk(ghost_tile ? *n_ghost_tiles : *n_tiles);
   int item;
-  while (walk.next(item)) {
-    const int tile = list[item];
+  bool have = walk.next(item);
+  TileSetupRegs next_rows;  // the NEXT tile's row loads travel under the current tile's sweep
+  if (have) tile_setup_load(c, tg, list[item], cell_start, next_rows);
+  while (have) {
     DSL_STAMP(t0);
     __syncthreads();
-    tile_setup(c, tg, tile, cell_start, m);
+    tile_setup_commit(next_rows, m);
+    have = walk.next(item);
     DSL_STAMP(t1);
     DSL_STAMP_ADD(0, t0, t1);
     const bool ovf = m.overflow != 0;
@@ -556,6 +577,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           });
     }
     __syncthreads();
+    if (have) tile_setup_load(c, tg, list[item], cell_start, next_rows);
     DSL_STAMP(t2);
     DSL_STAMP_ADD(1, t1, t2);
     const int ntarg = m.tprefix[kTB * kTB];
