@@ -549,6 +549,19 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     DSL_STAMP_ADD(0, t0, t1);
     const bool ovf = m.overflow != 0;
     const bool nolds = ovf || ghost_tile;  // owned targets of such a tile take the global-memory sweep
+    // The first pass's per-target mask words (valid word, first run word) are requested BEFORE the
+    // staging loads, so that their latency passes under the staging wait instead of in front of the sweep.
+    const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
+    unsigned int pre_valid = 0u, pre_word = 0u;
+    if (!nolds && nmask != nullptr && tperm < m.tprefix[kTB * kTB]) {
+      int srow0, off0;
+      tile_target(m, tperm, srow0, off0);
+      const int g0 = m.row_gs[srow0] + off0;
+      pre_valid = nmask[(size_t)kMaskValid * mstride + g0];
+      const float fy0 = (pin.y[g0] - c.gmin[1]) * c.inv_cell, fz0 = (pin.z[g0] - c.gmin[2]) * c.inv_cell;
+      const int sy0 = (fy0 - floorf(fy0)) >= 0.5f ? 1 : -1, sz0 = (fz0 - floorf(fz0)) >= 0.5f ? 1 : -1;
+      pre_word = nmask[(size_t)((1 - sz0) * 3 + (1 - sy0)) * mstride + g0];  // run_of(0) below
+    }
     if (!nolds) {
       stage_rows<8>(
           m, wid, lane,
@@ -581,7 +594,6 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     DSL_STAMP(t2);
     DSL_STAMP_ADD(1, t1, t2);
     const int ntarg = m.tprefix[kTB * kTB];
-    const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     // short passes are shared out as in k_density_tiled: k lanes per target, each walking every
     // k-th run; after the butterfly the group's first lane finishes the target
     for_each_target<SHARE>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
@@ -681,7 +693,9 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 xw_ += wx;
               }
             };
-            const unsigned int runs_masked = nmask != nullptr ? nmask[(size_t)kMaskValid * mstride + g] : 0u;
+            const bool first_pass = !SHARED && t == tperm;  // (its mask words were requested before the staging)
+            const unsigned int runs_masked =
+                first_pass ? pre_valid : (nmask != nullptr ? nmask[(size_t)kMaskValid * mstride + g] : 0u);
             DSL_STAMP(t4);
             DSL_STAMP_ADD(2, t3, t4);
             // Walk the in-range bits of one run (row rr of the staged tile, the 3 cells around the
@@ -730,7 +744,8 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               const int sy = (fy - floorf(fy)) >= 0.5f ? 1 : -1, sz = (fz - floorf(fz)) >= 0.5f ? 1 : -1;
               auto run_of = [&](int s) { return ((s / 3 - 1) * sz + 1) * 3 + ((s % 3 - 1) * sy + 1); };
               int rn = run_of(0);
-              unsigned int ahead = nmask != nullptr ? nmask[(size_t)rn * mstride + g] : 0u;  // (not behind runs_masked)
+              unsigned int ahead =
+                  first_pass ? pre_word : (nmask != nullptr ? nmask[(size_t)rn * mstride + g] : 0u);  // (not behind runs_masked)
               int jn, jen;
               run_bounds(rn, jn, jen);
 #pragma unroll 1
