@@ -9,7 +9,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-_LIB = os.path.join(_PKG, "lib", "libdslsph.so")
+# DSL_LIB: load another build of the same library (diagnostic builds, e.g. -DDSL_DIAG_STAMPS)
+_LIB = os.environ.get("DSL_LIB") or os.path.join(_PKG, "lib", "libdslsph.so")
 _SRC_DIR = os.path.join(_PKG, "csrc")
 _HDR = os.path.join(_ROOT, "include", "dslsph.h")
 

@@ -19,6 +19,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -65,6 +66,7 @@ struct dsl_handle {
   int* dev_tstats = nullptr;
   int tstats_seq = 0, tstats_seen = 0;
   bool share_short = false;
+  bool density_valu = false;  // diagnostic (env DSL_DENSITY_KERNEL=valu): k_density_tiled instead of k_density_quad
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -428,12 +430,17 @@ int density_pass(dsl_handle* h) {
     poll_tile_stats(h);
     int rc = timed(h, DSL_K_DENSITY, [&] {
       const int seq = ++h->tstats_seq;
-      if (h->share_short)
-        hipLaunchKernelGGL(k_density_tiled<true>, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq);
-      else
-        hipLaunchKernelGGL(k_density_tiled<false>, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                           h->tiles, h->n_tiles, h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq);
+#define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
+  hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, \
+                     h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq)
+      if (h->density_valu) {  // DSL_DENSITY_KERNEL=valu: the VALU-only sweep (same results bit for bit)
+        if (h->share_short) DSL_LAUNCH_DENSITY(k_density_tiled<true>);
+        else DSL_LAUNCH_DENSITY(k_density_tiled<false>);
+      } else {
+        if (h->share_short) DSL_LAUNCH_DENSITY(k_density_quad<true>);
+        else DSL_LAUNCH_DENSITY(k_density_quad<false>);
+      }
+#undef DSL_LAUNCH_DENSITY
     });
     if (rc) return rc;
     h->dens_fresh = true;
@@ -738,6 +745,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   if (!h) return fail(nullptr, DSL_ERR_NOMEM, "dsl_create: out of host memory");
   h->device = device;
   h->prm = *params;
+  if (const char* dk = std::getenv("DSL_DENSITY_KERNEL")) h->density_valu = std::strcmp(dk, "valu") == 0;
   int rc = make_consts(h, h->prm, h->c);
   if (rc) {
     g_create_error = h->err;
@@ -840,10 +848,13 @@ int dsl_destroy(dsl_handle* h) {
   (void)hipStreamSynchronize(h->stream);
 #ifdef DSL_DIAG_STAMPS
   {
-    unsigned long long d[8] = {};
+    unsigned long long d[32] = {};
     (void)hipMemcpyFromSymbol(d, HIP_SYMBOL(dsl::g_diag), sizeof(d));
-    std::fprintf(stderr, "[dsl diag] force kernel, wave-0 clocks: setup %llu staging %llu target-prologue %llu sweep %llu\n",
-                 d[0], d[1], d[2], d[3]);
+    std::fprintf(stderr,
+                 "[dsl diag] wave-0 clocks. force: setup %llu staging %llu (mask requests %llu, load issue %llu, wait+LDS "
+                 "%llu, barrier %llu) target-prologue %llu sweep %llu | density: setup %llu staging %llu (load issue %llu, "
+                 "wait+LDS %llu) sweep %llu\n",
+                 d[0], d[1], d[10], d[8], d[9], d[11], d[2], d[3], d[4], d[5], d[12], d[13], d[6]);
   }
 #endif
   free_all(h);
