@@ -66,7 +66,6 @@ struct dsl_handle {
   int* dev_tstats = nullptr;
   int tstats_seq = 0, tstats_seen = 0;
   bool share_short = false;
-  bool density_valu = false;  // diagnostic (env DSL_DENSITY_KERNEL=valu): k_density_tiled instead of k_density_quad
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -433,13 +432,8 @@ int density_pass(dsl_handle* h) {
 #define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
   hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, \
                      h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq)
-      if (h->density_valu) {  // DSL_DENSITY_KERNEL=valu: the VALU-only sweep (same results bit for bit)
-        if (h->share_short) DSL_LAUNCH_DENSITY(k_density_tiled<true>);
-        else DSL_LAUNCH_DENSITY(k_density_tiled<false>);
-      } else {
-        if (h->share_short) DSL_LAUNCH_DENSITY(k_density_quad<true>);
-        else DSL_LAUNCH_DENSITY(k_density_quad<false>);
-      }
+      if (h->share_short) DSL_LAUNCH_DENSITY(k_density_tiled<true>);
+      else DSL_LAUNCH_DENSITY(k_density_tiled<false>);
 #undef DSL_LAUNCH_DENSITY
     });
     if (rc) return rc;
@@ -745,7 +739,6 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   if (!h) return fail(nullptr, DSL_ERR_NOMEM, "dsl_create: out of host memory");
   h->device = device;
   h->prm = *params;
-  if (const char* dk = std::getenv("DSL_DENSITY_KERNEL")) h->density_valu = std::strcmp(dk, "valu") == 0;
   int rc = make_consts(h, h->prm, h->c);
   if (rc) {
     g_create_error = h->err;

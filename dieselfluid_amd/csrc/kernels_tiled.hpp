@@ -151,7 +151,8 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
     }
   }
 }
-__device__ __forceinline__ void tile_setup_commit(const TileSetupRegs& r, TileMeta& m) {
+// commit, first half (lanes < kTRows): the row table as loaded
+__device__ __forceinline__ void tile_setup_raw(const TileSetupRegs& r, TileMeta& m) {
   const int tid = threadIdx.x;
   if (tid < kTRows) {
     m.row_gs[tid] = r.s[0];
@@ -159,7 +160,10 @@ __device__ __forceinline__ void tile_setup_commit(const TileSetupRegs& r, TileMe
 #pragma unroll
     for (int k = 0; k <= kTH; ++k) m.cellS[tid * (kTH + 1) + k] = r.s[k] - r.s[0];
   }
-  __syncthreads();
+}
+// commit, second half (wave 0, behind a barrier): LDS offsets of the rows and the target prefix
+__device__ __forceinline__ void tile_setup_scan(TileMeta& m) {
+  const int tid = threadIdx.x;
   if (tid < kWave) {  // wave 0: exclusive prefix of (len + pad) over the 36 rows
     const int v = tid < kTRows ? m.row_len[tid] + kTPad : 0;
     const int inc = wave_inclusive_scan(v);
@@ -178,6 +182,11 @@ __device__ __forceinline__ void tile_setup_commit(const TileSetupRegs& r, TileMe
     if (tid < kTB * kTB) m.tprefix[tid] = tinc - tv;
     if (tid == kTB * kTB - 1) m.tprefix[kTB * kTB] = tinc;
   }
+}
+__device__ __forceinline__ void tile_setup_commit(const TileSetupRegs& r, TileMeta& m) {
+  tile_setup_raw(r, m);
+  __syncthreads();
+  tile_setup_scan(m);
   __syncthreads();
 }
 __device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& tg, int tile,
@@ -293,13 +302,6 @@ __device__ __forceinline__ float fma_clamp01(float a, float b, float c) {
   return d;
 }
 
-// max(-x, 0) for x >= -1 in one instruction, the [0, 1] clamp (source negation and clamp are VOP3
-// modifiers).  fminf(x, 0) would cost two: the compiler puts a canonicalising v_max_f32 x, x in front of
-// the v_min_f32 when it cannot see that x is the result of an arithmetic instruction (an MFMA result).
-// (NOT inline assembly: the compiler pads no MFMA -> VALU wait states in front of an asm statement,
-// which then reads the accumulator before the MFMA has written it.)
-__device__ __forceinline__ float clamp01_neg(float x) { return __builtin_amdgcn_fmed3f(-x, 0.0f, 1.0f); }
-
 // mask = 2*mask + (q > 0): compare into VCC, then add-with-carry shifts the bit in
 __device__ __forceinline__ void mask_push(unsigned int& mask, float q) {
   asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(q) : "vcc");
@@ -310,33 +312,46 @@ __device__ __forceinline__ void mask_push(unsigned int& mask, float q) {
 // global-memory latency instead of one per row; rows longer than 64 records finish in a loop.
 constexpr int kRowsPerWave = (kTRows + kTBlock / kWave - 1) / (kTBlock / kWave);  // 5
 
-template <int NF, class Load, class Store>
-__device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane, Load&& load, Store&& store) {
-  float reg[kRowsPerWave][NF];
-  bool have[kRowsPerWave];
-  DSL_STAMP(s0);
+template <int NF>
+struct StageRegs {
+  float v[kRowsPerWave][NF];
+};
+// issue: one record per lane and row into registers; nothing waits here.  Needs row_gs / row_len only.
+template <int NF, class Load>
+__device__ __forceinline__ void stage_issue(const TileMeta& m, int wid, int lane, Load&& load, StageRegs<NF>& sr) {
 #pragma unroll
   for (int k = 0; k < kRowsPerWave; ++k) {
     const int r = wid + k * (kTBlock / kWave);
-    have[k] = r < kTRows && lane < m.row_len[r];
-    if (have[k]) load(m.row_gs[r] + lane, reg[k]);
+    if (r < kTRows && lane < m.row_len[r]) load(m.row_gs[r] + lane, sr.v[k]);
   }
-  DSL_STAMP(s1);
-  DSL_STAMP_ADD(NF == 8 ? 8 : 12, s0, s1);  // staging: load issue
+}
+// commit: registers -> LDS records, the rest of rows longer than 64, the pad records
+template <int NF, class Load, class Store>
+__device__ __forceinline__ void stage_commit(const TileMeta& m, int wid, int lane, const StageRegs<NF>& sr, Load&& load,
+                                             Store&& store) {
 #pragma unroll
   for (int k = 0; k < kRowsPerWave; ++k) {
     const int r = wid + k * (kTBlock / kWave);
     if (r >= kTRows) continue;
     const int len = m.row_len[r], ls = m.row_lds[r];
-    if (lane < len) store(ls + lane, reg[k], true);
+    if (lane < len) store(ls + lane, sr.v[k], true);
     for (int i = lane + kWave; i < len; i += kWave) {  // rare: more than 64 particles in the row
       float t[NF];
       load(m.row_gs[r] + i, t);
       store(ls + i, t, true);
     }
     const int npad = m.row_lds[r + 1] - ls - len;
-    if (lane < npad) store(ls + len + lane, reg[k], false);
+    if (lane < npad) store(ls + len + lane, sr.v[k], false);
   }
+}
+template <int NF, class Load, class Store>
+__device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane, Load&& load, Store&& store) {
+  StageRegs<NF> sr;
+  DSL_STAMP(s0);
+  stage_issue<NF>(m, wid, lane, load, sr);
+  DSL_STAMP(s1);
+  DSL_STAMP_ADD(NF == 8 ? 8 : 12, s0, s1);  // staging: load issue
+  stage_commit<NF>(m, wid, lane, sr, load, store);
   DSL_STAMP(s2);
   DSL_STAMP_ADD(NF == 8 ? 9 : 13, s1, s2);  // staging: wait for the data + LDS writes
 }
@@ -384,7 +399,11 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
                                                           float* __restrict__ rho, float* __restrict__ pterm,
                                                           unsigned int* __restrict__ nmask, int mstride,
                                                           volatile int* __restrict__ host_stats, int stats_seq) {
-  __shared__ TileMeta m;
+  // Tiles are pipelined across the loop: while tile T is swept, the records of tile T+1 are on their
+  // way from HBM into registers (15 per lane) and the row table of tile T+2 likewise (7 per lane), so a
+  // tile's set-up and staging cost two barriers and some LDS writes instead of two memory round trips
+  // (per-phase clocks before: sweep 45 %, staging 35 %, set-up 20 % of a tile's life; profiles/r02_*).
+  __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
   // tile statistics of this neighbour build, written straight into host-mapped memory for the
@@ -395,43 +414,55 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     __threadfence_system();
     host_stats[2] = stats_seq;
   }
+  auto load_rec = [&](int g, float* o) {
+    o[0] = p.x[g];
+    o[1] = p.y[g];
+    o[2] = p.z[g];
+  };
   TileFeed feed(tiles, *n_tiles);
-  TileSetupRegs next_rows;  // the NEXT tile's row loads travel under the current tile's sweep
-  int tile = 0;
-  bool have = feed.pop(tile);
-  if (have) tile_setup_load(c, tg, tile, cell_start, next_rows);
-  while (have) {
+  TileSetupRegs rows;   // row table of the tile after the one whose records are in flight
+  StageRegs<3> recs;    // records of the next tile to be swept
+  int tile = 0, tile_next = 0, tile_after = 0;
+  if (!feed.pop(tile)) return;
+  tile_setup_load(c, tg, tile, cell_start, rows);
+  tile_setup_commit(rows, metas[0]);
+  stage_issue<3>(metas[0], wid, lane, load_rec, recs);
+  bool have_next = feed.pop(tile_next);
+  if (have_next) tile_setup_load(c, tg, tile_next, cell_start, rows);
+  for (int cur = 0;; cur ^= 1) {
+    TileMeta& m = metas[cur];
+    TileMeta& mn = metas[cur ^ 1];
     DSL_STAMP(d0);
-    __syncthreads();  // previous tile's LDS is no longer read
-    tile_setup_commit(next_rows, m);
+    __syncthreads();  // the previous tile's sweep is over: its LDS records and the other row table are free
     DSL_STAMP(d1);
     DSL_STAMP_ADD(4, d0, d1);
-    const int cur_tile = tile;
-    have = feed.pop(tile);
     const bool ovf = m.overflow != 0;
     // tile centre in world coordinates
-    const float ox = c.gmin[0] + ((cur_tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
-    const float oy = c.gmin[1] + (((cur_tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
-    const float oz = c.gmin[2] + ((cur_tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
+    const float ox = c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
+    const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
+    const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
-      stage_rows<3>(
-          m, wid, lane,
-          [&](int g, float* o) {
-            o[0] = p.x[g];
-            o[1] = p.y[g];
-            o[2] = p.z[g];
-          },
-          [&](int slot, const float* o, bool real) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
-            if (real) {
-              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
-              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-            }
-            A[slot] = v;
-          });
+      stage_commit<3>(m, wid, lane, recs, load_rec, [&](int slot, const float* o, bool real) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+        if (real) {
+          const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+          v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+        }
+        A[slot] = v;
+      });
     }
+    if (have_next) tile_setup_raw(rows, mn);
     __syncthreads();
-    if (have) tile_setup_load(c, tg, tile, cell_start, next_rows);
+    bool have_after = false;
+    if (have_next) {
+      // wave 0 finishes the next tile's table (read again only behind the next barrier) while every
+      // wave requests that tile's records (which need row_gs / row_len only) ...
+      if (wid == 0) tile_setup_scan(mn);
+      stage_issue<3>(mn, wid, lane, load_rec, recs);
+      // ... and the row table of the tile after it
+      have_after = feed.pop(tile_after);
+      if (have_after) tile_setup_load(c, tg, tile_after, cell_start, rows);
+    }
     DSL_STAMP(d2);
     DSL_STAMP_ADD(5, d1, d2);
     const int ntarg = m.tprefix[kTB * kTB];
@@ -532,265 +563,10 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     });
     DSL_STAMP(d3);
     DSL_STAMP_ADD(6, d2, d3);
-  }
-}
-
-// ---------------------------------------------------------------------------------
-// D (tiled, quads on the matrix pipe): the same densities, P/rho^2 and neighbour masks as
-// k_density_tiled, bit for bit, with the distance test q_ij moved from the VALU to the f32 MFMA.
-//
-// Why: k_density_tiled spends 4 of its 7 VALU instructions per candidate on q and reads one
-// float4 from LDS per candidate and lane; at 4 waves per SIMD it ran at 3.9 clocks per VALU
-// instruction with the LDS 63 % busy (profiles/r01_final5_pmc.md): VALU issue and LDS bandwidth
-// co-limit it.  v_mfma_f32_4x4x1_16b_f32 computes sixteen independent 4x4 outer products per
-// wave: block b (lanes 4b..4b+3) gets D[v][lane] += A[lane 4b+v] * B[lane].  With the four lanes
-// of a block holding four targets OF THE SAME CELL (same candidate runs) and lane 4b+v supplying
-// candidate v of a chunk of four, four chained MFMAs (K = w, x, y, z; the chain is bit for bit the
-// fmaf chain of k_density_tiled, MI355X_MICROARCH.md "f32-input MFMA") leave the q of candidates
-// v = 0..3 against the lane's own target in D[0..3].  Per chunk of 4 candidates a lane now issues ONE
-// ds_read_b128 (was 4) and 12 VALU instructions (was 28: sign push, clamp, accumulate), and the
-// matrix pipe co-executes with the VALU of the other waves.
-//
-// The sign trick: the chain computes -q (all constants negated, exact), so that the sign bit of the
-// result IS the neighbour bit (q > 0) and one v_alignbit_b32 shifts it into the mask.
-//
-// Everything in the sweep is wave-uniform (MFMA ignores EXEC): a lane whose run is shorter than the
-// wave's longest keeps going on a far-away pad record, which pushes 0 bits and adds 0; the surplus
-// bits are shifted out again after the run (run lengths differ between the cells of a wave once the
-// lattice has melted).  Quads beyond the tile's last and the unused lanes of a cell's last quad
-// duplicate a real target and skip the stores.
-// ---------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int kQuadsPerPass = kTBlock / 4;
-constexpr int kQuadCap = (kTCap + 3 * kTB * kTB * kTB) / 4;  // quads of a staged tile: sum over cells of ceil(n/4)
-
-struct TileQuads {
-  int nquads;
-  unsigned short qmap[kQuadCap];  // quad -> interior cell (bits 0-5: x | y<<2 | z<<4) | quad-in-cell << 6
-};
-
-// wave 0, after tile_setup_commit: one lane per interior cell
-__device__ __forceinline__ void tile_quads(const TileMeta& m, TileQuads& tq) {
-  const int lane = threadIdx.x & (kWave - 1);
-  const int rr = ((lane >> 4) + 1) * kTH + ((lane >> 2) & 3) + 1, lx = (lane & 3) + 1;
-  const int cnt = m.cellS[rr * (kTH + 1) + lx + 1] - m.cellS[rr * (kTH + 1) + lx];
-  const int nq = (cnt + 3) >> 2;
-  const int inc = wave_inclusive_scan(nq);
-  for (int k = 0, at = inc - nq; k < nq && at < kQuadCap; ++k, ++at) tq.qmap[at] = (unsigned short)(lane | (k << 6));
-  if (lane == kWave - 1) tq.nquads = inc < kQuadCap ? inc : kQuadCap;  // (more only in a tile that overflowed LDS anyway)
-}
-
-// Quad slot of a lane inside its wave for the full passes.  ds_read_b128 serves lanes in the groups
-// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): quads {0,3,5,6}, {1,2,4,7} (+8).  Consecutive quads
-// mostly belong to the same or the x-adjacent cell, whose runs start 8 records = 128 bytes apart; a
-// group that holds four consecutive quads therefore reads two 64-byte pieces half a bank row apart.
-__device__ __forceinline__ int quad_slot_in_wave(int lane) {
-  const int s = lane >> 2;
-  return (s & 8) | ((0x73261540u >> (4 * (s & 7))) & 7u);
-}
-
-template <bool SHARE>
-__global__ __launch_bounds__(kTBlock) void k_density_quad(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
-                                                         const int* __restrict__ n_tiles,
-                                                         const int* __restrict__ cell_start, CSoa3 p,
-                                                         float* __restrict__ rho, float* __restrict__ pterm,
-                                                         unsigned int* __restrict__ nmask, int mstride,
-                                                         volatile int* __restrict__ host_stats, int stats_seq) {
-  __shared__ TileMeta m;
-  __shared__ TileQuads tq;
-  __shared__ float4 A[kTCap];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6, u = tid & 3;
-  if (host_stats != nullptr && blockIdx.x == 0 && tid == 0) {  // tile statistics, as in k_density_tiled
-    host_stats[0] = n_tiles[0];
-    host_stats[1] = n_tiles[5];
-    __threadfence_system();
-    host_stats[2] = stats_seq;
-  }
-  TileFeed feed(tiles, *n_tiles);
-  TileSetupRegs next_rows;
-  int tile = 0;
-  bool have = feed.pop(tile);
-  if (have) tile_setup_load(c, tg, tile, cell_start, next_rows);
-  while (have) {
-    __syncthreads();  // previous tile's LDS is no longer read
-    tile_setup_commit(next_rows, m);
-    if (wid == 0) tile_quads(m, tq);  // (visible to the other waves after the staging barrier)
-    const int cur_tile = tile;
-    have = feed.pop(tile);
-    const bool ovf = m.overflow != 0;
-    const float ox = c.gmin[0] + ((cur_tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
-    const float oy = c.gmin[1] + (((cur_tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
-    const float oz = c.gmin[2] + ((cur_tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
-    if (!ovf) {
-      stage_rows<3>(
-          m, wid, lane,
-          [&](int g, float* o) {
-            o[0] = p.x[g];
-            o[1] = p.y[g];
-            o[2] = p.z[g];
-          },
-          [&](int slot, const float* o, bool real) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: -q = +1e30: no bit, no contribution
-            if (real) {
-              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
-              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-            }
-            A[slot] = v;
-          });
-    }
-    __syncthreads();
-    if (have) tile_setup_load(c, tg, tile, cell_start, next_rows);
-    // per-target epilogue shared by both paths: rho, P/rho^2, valid word
-    auto finish = [&](int g, float acc, unsigned int mvalid, bool from_lds) {
-      if (from_lds) acc = (acc - 1.0f) * (c.mass * c.A);  // the particle met itself once (q = 1)
-      rho[g] = acc;
-      nmask[(size_t)kMaskValid * mstride + g] = mvalid;
-      const float pr = tait_eos<true>(c, acc, c.eos_d0_grad);
-      pterm[g] = acc > 0.0f ? dsl_div<true>(pr, acc * acc) : 0.0f;  // (isolated particle: see k_density_tiled)
-    };
-    if (ovf) {  // the halo does not fit LDS: global-memory sweep, one lane per target, no masks
-      const int ntarg = m.tprefix[kTB * kTB];
-      for (int t = tid; t < ntarg; t += kTBlock) {
-        int srow, off;
-        tile_target(m, t, srow, off);
-        const int g = m.row_gs[srow] + off;
-        const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
-        float acc = 0.0f;
-        for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
-          if (j == g) return;
-          const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
-          const float r2 = dist2<true>(dx, dy, dz);
-          if (r2 < c.hh) {
-            const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
-            acc = __builtin_fmaf(c.mass * c.A, q * q, acc);
-          }
-        });
-        finish(g, acc, 0u, false);
-      }
-      continue;
-    }
-    const int nq = tq.nquads;
-    const int pad_rec = m.row_lds[1] - kTPad;  // first pad record of staged row 0
-    for (int qbase = 0; qbase < nq;) {
-      const int rem = nq - qbase;
-      // A short last pass is shared out as in k_density_tiled: 2, 4 or 8 quads per target quad, each
-      // sweeping every k-th run; the partial sums meet in a butterfly over lanes 4, 8, 16 apart.
-      int sh = 0;
-      if constexpr (SHARE)
-        sh = rem > kQuadsPerPass / 2 ? 0 : (rem > kQuadsPerPass / 4 ? 1 : (rem > kQuadsPerPass / 8 ? 2 : 3));
-      const int k = 1 << sh;
-      qbase += min(rem, kQuadsPerPass >> sh);
-      if (((wid * (kWave / 4)) >> sh) >= rem) continue;  // wave without a live quad (wave-uniform)
-      const int slot = wid * (kWave / 4) + (sh == 0 ? quad_slot_in_wave(lane) : (lane >> 2));
-      const int ql = slot >> sh, sub = slot & (k - 1);
-      const bool qvalid = ql < rem;
-      const unsigned int e = tq.qmap[nq - rem + (qvalid ? ql : rem - 1)];
-      const int cc = e & 63, kq = e >> 6;
-      const int lx = (cc & 3) + 1, srow = ((cc >> 4) + 1) * kTH + ((cc >> 2) & 3) + 1;
-      const int c0 = m.cellS[srow * (kTH + 1) + lx], cnt = m.cellS[srow * (kTH + 1) + lx + 1] - c0;
-      const int toff = 4 * kq + u;
-      const bool tvalid = qvalid && toff < cnt;
-      const int off = c0 + min(toff, cnt - 1);
-      const int g = m.row_gs[srow] + off;
-      const float4 me = A[m.row_lds[srow] + off];
-      const float n2hh = -2.0f * c.inv_hh;
-      const float nsx = n2hh * me.x, nsy = n2hh * me.y, nsz = n2hh * me.z, na0 = -(1.0f + me.w);
-      const f32x4_t cin = {na0, na0, na0, na0};
-      float acc = 0.0f, acc1 = 0.0f;
-      unsigned int mvalid = 0u;
-      // two chunks of four candidates: D = -(a0 + w_j + sx x_j + sy y_j + sz z_j) = -q, candidate v in D[v]
-      auto test8 = [&](const float4& r0, const float4& r1, unsigned int& mask) {
-        f32x4_t d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.w, -1.0f, cin, 0, 0, 0);
-        f32x4_t d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.w, -1.0f, cin, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.x, nsx, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.x, nsx, d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.y, nsy, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.y, nsy, d1, 0, 0, 0);
-        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.z, nsz, d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.z, nsz, d1, 0, 0, 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d0[v]), 31);  // mask = 2 mask + (q > 0)
-          const float t = clamp01_neg(d0[v]);
-          if (v & 1) acc1 = __builtin_fmaf(t, t, acc1);
-          else acc = __builtin_fmaf(t, t, acc);
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d1[v]), 31);
-          const float t = clamp01_neg(d1[v]);
-          if (v & 1) acc1 = __builtin_fmaf(t, t, acc1);
-          else acc = __builtin_fmaf(t, t, acc);
-        }
-      };
-      // up to 32 candidates [jb, jend) of one run -> one mask word (bit order as k_density_tiled: the
-      // first candidate is the highest of the ((n + 3) & ~3) bits used).  Eight candidates per trip,
-      // the next trip's records requested before the current trip's arithmetic; `keep` is a use of
-      // the prefetched records on the exit path (without it the compiler sinks their LDS reads below
-      // the branch and the prefetch is gone).
-      auto sweep_word = [&](int jb, int jend) {
-        auto ld = [&](int x) { return A[x < jend ? x + u : pad_rec]; };
-        auto any_from = [&](int x) { return __builtin_amdgcn_ballot_w64(x < jend) != 0ull; };
-        auto keep = [](const float4& r0, const float4& r1) {  // (every component: a single one and the read is split)
-          asm volatile("" ::"v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));
-        };
-        unsigned int mask = 0u;
-        int trips = 1;
-        float4 a0 = ld(jb), a1 = ld(jb + 4), b0 = ld(jb + 8), b1 = ld(jb + 12);
-        test8(a0, a1, mask);
-        if (any_from(jb + 8)) {
-          a0 = ld(jb + 16);
-          a1 = ld(jb + 20);
-          test8(b0, b1, mask);
-          trips = 2;
-          if (any_from(jb + 16)) {
-            b0 = ld(jb + 24);
-            b1 = ld(jb + 28);
-            test8(a0, a1, mask);
-            trips = 3;
-            if (any_from(jb + 24)) {
-              test8(b0, b1, mask);
-              trips = 4;
-            } else {
-              keep(b0, b1);
-            }
-          } else {
-            keep(a0, a1);
-          }
-        } else {
-          keep(b0, b1);
-        }
-        // the lane's own candidates came first; the pad chunks behind them pushed zeros
-        const int own = min(max((jend - jb + 3) >> 2, 0), 8);
-        return own > 0 ? mask >> (8 * trips - 4 * own) : 0u;
-      };
-#pragma unroll 1
-      for (int ri = sub; ri < 9; ri += k) {
-        const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
-        const int rb = m.row_lds[rr];
-        const int jb = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-        const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-        if (je - jb <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: the force pass sweeps this run in full
-        unsigned int w0 = 0u;
-        if (__builtin_amdgcn_ballot_w64(jb < je) != 0ull) w0 = sweep_word(jb, min(je, jb + 32));
-        if (tvalid) nmask[(size_t)ri * mstride + g] = w0;
-        if (__builtin_amdgcn_ballot_w64(je > jb + 32) != 0ull) {  // candidates 32-63 (rare)
-          const unsigned int w1 = sweep_word(jb + 32, min(je, jb + 64));
-          if (tvalid && je > jb + 32) nmask[(size_t)(kMaskHigh + ri) * mstride + g] = w1;
-          if (__builtin_amdgcn_ballot_w64(je > jb + 64) != 0ull) {  // beyond the masks: density only
-            for (int jc = jb + 64; __builtin_amdgcn_ballot_w64(jc < je) != 0ull; jc += 32) (void)sweep_word(jc, min(je, jc + 32));
-          }
-        }
-      }
-      acc += acc1;
-      if constexpr (SHARE) {
-        for (int o = 1; o < k; o <<= 1) {  // the sub-quads of a target quad are 4, 8, 16 lanes apart
-          acc += __shfl_xor(acc, 4 * o, kWave);
-          mvalid |= __shfl_xor(mvalid, 4 * o, kWave);
-        }
-      }
-      if (tvalid && sub == 0) finish(g, acc, mvalid, true);
-    }
+    if (!have_next) break;
+    tile = tile_next;
+    tile_next = tile_after;
+    have_next = have_after;
   }
 }
 
