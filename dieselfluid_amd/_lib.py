@@ -41,7 +41,8 @@ class Params(C.Structure):
         ("grid_min", C.c_float * 3), ("grid_max", C.c_float * 3),
         ("neigh_mode", C.c_int32), ("math_mode", C.c_int32), ("capacity", C.c_int32),
         ("xsph_eps", C.c_float), ("st_kappa", C.c_float),
-        ("reserved", C.c_int32 * 5),
+        ("sort_unordered", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

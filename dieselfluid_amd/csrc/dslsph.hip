@@ -77,6 +77,10 @@ struct dsl_handle {
   unsigned int* nmask = nullptr;  // FAST: per-particle in-range masks from the density sweep (kMaskWords x cap)
   bool masks_valid = false;
   int *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
+  // in-cell ordering of the counting sort (kernels_grid.hpp, k_scatter): bitmap of the cells to order,
+  // their ids at the slots the atomic ranks name, work list of their particles
+  unsigned int* unordered = nullptr;
+  int *sort_keys = nullptr, *sort_work = nullptr;
   float* stage = nullptr;
   DevStats* dstats = nullptr;
   int cur_pv = 0, cur_ids = 0, cur_f = 0, cur_pci = 0;
@@ -309,15 +313,17 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
   HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+  const bool ordered = !h->prm.sort_unordered;
+  if (ordered) HIP_TRY(h, hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream));
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
-    hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z, h->rank,
-                       h->cell_count);
+    hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
+                       ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
     hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan, h->dstats,
-                       h->prm.math_mode == DSL_MATH_FAST ? h->n_tiles : nullptr);
+                       h->prm.math_mode == DSL_MATH_FAST ? h->n_tiles : nullptr, h->dcounter + 1);
     hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
                        h->cell_start, h->dstats);
   });
@@ -339,26 +345,26 @@ int build_grid(dsl_handle* h, bool carry_derived) {
       a.src[nf] = h->pci[h->cur_pci][k];
       a.dst[nf++] = h->pci[h->cur_pci ^ 1][k];
     }
-  // derived arrays travel through the scratch buffer one at a time (rare path)
   a.nf = nf;
   a.ids_src = h->ids[h->cur_ids];
   a.ids_dst = h->ids[h->cur_ids ^ 1];
+  // derived arrays (an explicit dsl_build_neighbours behind a density pass: rare) follow through the
+  // particles' final slots, which the scatter leaves in place of the ranks
+  float* derived[3] = {(carry_derived && h->dens_fresh) ? h->rho : nullptr, (carry_derived && h->dens_fresh) ? h->pterm : nullptr,
+                       (carry_derived && !h->press_zero) ? h->press : nullptr};
+  const bool want_dest = derived[0] || derived[1] || derived[2];
+  ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, h->sort_work, h->dcounter + 1, want_dest ? h->rank : nullptr};
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, p, h->rank, h->cell_start);
+    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
+    if (ordered)
+      hipLaunchKernelGGL(k_scatter_ordered, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank,
+                         h->cell_start);
   });
   if (rc) return rc;
   if (carry_derived) {
-    float* derived[3] = {h->dens_fresh ? h->rho : nullptr, h->dens_fresh ? h->pterm : nullptr,
-                         h->press_zero ? nullptr : h->press};
     for (float* arr : derived) {
       if (!arr) continue;
-      ScatterArrays b{};
-      b.src[0] = arr;
-      b.dst[0] = h->scratch1;
-      b.nf = 1;
-      b.ids_src = h->ids[h->cur_ids];      // ids re-scattered identically; harmless
-      b.ids_dst = h->ids[h->cur_ids ^ 1];
-      hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, b, p, h->rank, h->cell_start);
+      hipLaunchKernelGGL(k_permute1, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, h->rank, p, arr, h->scratch1);
       HIP_TRY(h, hipGetLastError());
       HIP_TRY(h, hipMemcpyAsync(arr, h->scratch1, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -639,6 +645,9 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->press);
   (void)hipFree(h->scratch1);
   (void)hipFree(h->rank);
+  (void)hipFree(h->sort_keys);
+  (void)hipFree(h->sort_work);
+  (void)hipFree(h->unordered);
   (void)hipFree(h->cell_count);
   (void)hipFree(h->cell_start);
   (void)hipFree(h->block_sums);
@@ -770,7 +779,8 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     if ((rc = dev_alloc(h, &h->ids[w], n))) return bail(rc);
   }
   if ((rc = dev_alloc(h, &h->rho, n)) || (rc = dev_alloc(h, &h->pterm, n)) || (rc = dev_alloc(h, &h->press, n)) ||
-      (rc = dev_alloc(h, &h->scratch1, n)) || (rc = dev_alloc(h, &h->rank, n)) ||
+      (rc = dev_alloc(h, &h->scratch1, n)) || (rc = dev_alloc(h, &h->rank, n)) || (rc = dev_alloc(h, &h->sort_keys, n)) ||
+      (rc = dev_alloc(h, &h->sort_work, n)) || (rc = dev_alloc(h, &h->unordered, (size_t)h->ncell_pad / 32)) ||
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||

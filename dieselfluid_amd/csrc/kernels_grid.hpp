@@ -7,6 +7,8 @@
 // BASELINE.json's north_star asks; gfx950 only.
 #pragma once
 
+#include <climits>
+
 #include "sph_device.hpp"
 
 namespace dsl {
@@ -30,18 +32,28 @@ __device__ __forceinline__ int sort_cell(const DevConsts& c, float x, float y, f
   return cell_of(c, x, y, z);
 }
 
+// `unordered` is a bitmap over the cells: a set bit marks a cell whose slot order the scatter has to
+// establish (see k_scatter): it received more than one run, or a run that was not ascending in
+// particle id.  A lattice at rest has neither (a cell's particles are one run, in the order the
+// previous step left them), so the ordering costs next to nothing there.
 __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* __restrict__ px,
                                                       const float* __restrict__ py,
-                                                      const float* __restrict__ pz, int* __restrict__ rank,
-                                                      int* __restrict__ cell_count) {
+                                                      const float* __restrict__ pz, const int* __restrict__ ids,
+                                                      int* __restrict__ rank, int* __restrict__ cell_count,
+                                                      unsigned int* __restrict__ unordered) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
-  int cell = -1;
+  int cell = -1, id = 0;
   const int n = live_n(c);
-  if (i < n) cell = sort_cell(c, px[i], py[i], pz[i]);
-  const int prev = __shfl_up(cell, 1, kWave);
+  if (i < n) {
+    cell = sort_cell(c, px[i], py[i], pz[i]);
+    if (ids) id = ids[i];
+  }
+  const int prev = __shfl_up(cell, 1, kWave), prev_id = __shfl_up(id, 1, kWave);
   const bool head = (lane == 0) || (cell != prev);
   const unsigned long long heads = __ballot(head);
+  // lanes that break the ascending-id order of their run (ids == nullptr: nobody asks for an order)
+  const unsigned long long breaks = __ballot(ids != nullptr && !head && id <= prev_id);
   const unsigned long long le = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
   const int head_lane = 63 - __builtin_clzll(le);  // le always has bit 0 set
   const unsigned long long above = (head_lane == 63) ? 0ull : (heads & ~((2ull << head_lane) - 1ull));
@@ -49,7 +61,11 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   const int run = next - head_lane;
   int base = 0;
   // (a whole band of stale ghosts would otherwise hammer one counter: same-address atomics serialise)
-  if (lane == head_lane && cell >= 0 && cell != c.ncell) base = atomicAdd(&cell_count[cell], run);
+  if (lane == head_lane && cell >= 0 && cell != c.ncell) {
+    base = atomicAdd(&cell_count[cell], run);
+    const unsigned long long mine = (next == kWave ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << head_lane) - 1ull);
+    if (ids != nullptr && (base != 0 || (breaks & mine) != 0ull)) atomicOr(&unordered[cell >> 5], 1u << (cell & 31));
+  }
   base = __shfl(base, head_lane, kWave);
   if (i < n) rank[i] = base + (lane - head_lane);  // (the scatter recomputes the cell: cheaper than 8 B of traffic)
 }
@@ -105,9 +121,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ co
 // and everything that follows it, so it also clears the small counters of the later kernels
 // (the fullest-cell statistic of phase 3, the tile-list lengths) instead of two more memsets.
 __global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sums, int nb, DevStats* stats,
-                                                     int* __restrict__ n_tiles) {
+                                                     int* __restrict__ n_tiles, int* __restrict__ n_work) {
   __shared__ int lds[kBlock / kWave];
   if (threadIdx.x == 0) stats->max_cell_count = 0;
+  if (threadIdx.x == 0) *n_work = 0;
   if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
   int carry = 0;
   for (int base = 0; base < nb; base += kBlock) {
@@ -165,17 +182,85 @@ struct ScatterArrays {
   int* ids_dst;
 };
 
+// Deterministic in-cell order.  k_cell_rank's rank inside the cell is the order in which the waves'
+// atomics happened to land, different from run to run -- and with it the order of every neighbour
+// sum, i.e. the last bits of every result.  The particles of the cells k_cell_rank has marked (more
+// than one run, or a run not ascending in id) are therefore scattered in two steps: k_scatter only puts
+// their ids at the slots the atomic ranks name and their indices on a work list; k_scatter_ordered then
+// lets every one of them count the ids of its cell that are smaller than its own and take that slot.
+// Slots inside a cell are then ascending in particle id whatever the atomics did: the order of the
+// oracle's DSLO_ORDER_CELL and, cell by cell, of the reference's bucket lists (lsh.go:113-118 appends
+// in particle order).  Equal ids (there should be none) keep the atomic order among themselves.
+struct ScatterOrder {
+  const unsigned int* unordered;  // bitmap from k_cell_rank; nullptr = keep the order the atomics left
+  int* keys;                      // ids at the atomic slots (marked cells only)
+  int* work;                      // indices of the particles of marked cells
+  int* n_work;
+  int* dest;                      // optional: final slot of every particle (to permute derived arrays)
+};
+
+__device__ __forceinline__ void scatter_move(const ScatterArrays& a, const ScatterOrder& o, int i, int d, int id) {
+  a.ids_dst[d] = id;
+  for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
+  if (o.dest) o.dest[i] = d;
+}
+
 // `pos`: the unsorted positions the ranks were computed from
-__global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, CSoa3 pos,
+__global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  bool later = false;
+  int cell = 0;
+  if (i < live_n(c)) {
+    cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+    if (cell != c.ncell) {  // (a stale ghost is dropped)
+      const int id = a.ids_src[i];
+      const int d = cell_start[cell] + rank[i];
+      later = o.unordered != nullptr && ((o.unordered[cell >> 5] >> (cell & 31)) & 1u);
+      if (later) o.keys[d] = id;
+      else scatter_move(a, o, i, d, id);
+    }
+  }
+  const unsigned long long m = __ballot(later);  // one atomic per wave
+  if (m != 0ull) {
+    const int leader = __builtin_ctzll(m);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(o.n_work, __builtin_popcountll(m));
+    base = __shfl(base, leader, kWave);
+    if (later) o.work[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
+                                                            const int* __restrict__ rank,
+                                                            const int* __restrict__ cell_start) {
+  const int w = blockIdx.x * kBlock + threadIdx.x;
+  if (w >= *o.n_work) return;
+  const int i = o.work[w];
   const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
-  if (cell == c.ncell) return;  // stale ghost: dropped
-  const int d = cell_start[cell] + rank[i];
-  a.ids_dst[d] = a.ids_src[i];
-  for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
+  const int id = a.ids_src[i];
+  const int s = cell_start[cell], e = cell_start[cell + 1], mine = s + rank[i];
+  int below = 0;
+  // eight ids per trip, all eight loads in flight together (a cell holds ~8)
+  for (int k0 = s; k0 < e; k0 += 8) {
+    int key[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) key[u] = k0 + u < e ? o.keys[k0 + u] : INT_MAX;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) below += (key[u] < id || (key[u] == id && k0 + u < mine)) ? 1 : 0;
+  }
+  scatter_move(a, o, i, s + below, id);
+}
+
+// dst[dest[i]] = src[i]: a derived per-particle array follows the sort
+__global__ __launch_bounds__(kBlock) void k_permute1(DevConsts c, const int* __restrict__ dest, CSoa3 pos,
+                                                     const float* __restrict__ src, float* __restrict__ dst) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= live_n(c)) return;
+  if (sort_cell(c, pos.x[i], pos.y[i], pos.z[i]) == c.ncell) return;  // stale ghost: dropped, dest[i] not written
+  dst[dest[i]] = src[i];
 }
 
 // ---------------------------------------------------------------------------------
@@ -439,7 +524,7 @@ __device__ __forceinline__ void slab_counts(const float* msg, int cap_full, int 
 }
 
 // appends the records of up to two messages behind the current particles: per message the full
-// records first, then the position-only ones (velocity 0, id -1: they are ghosts by construction).
+// records first, then the position-only ones (velocity 0, a negative id: they are ghosts by construction).
 // blockIdx.y selects the message; the second one lands behind the first.
 __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg0,
                                                         const float* __restrict__ msg1, int cap_full, int cap_x,
@@ -490,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
     vx[d] = 0.f;
     vy[d] = 0.f;
     vz[d] = 0.f;
-    ids[d] = -1;
+    ids[d] = -2 - (int)(blockIdx.y * cap_x + j);  // negative = position-only ghost; distinct: the sort orders a cell by id
     if (rec == kRecordPci) {  // ghosts: never predicted, any finite value will do
       pcip.x[d] = r[0];
       pcip.y[d] = r[1];

@@ -105,7 +105,12 @@ typedef struct dsl_params {
    *   xsph_eps: positions advect with v + eps * sum_j (m/rho_j) (v_j - v_i) F(r_ij)
    *   st_kappa: cohesion force F_i += kappa * sum_j m (x_j - x_i) F(r_ij)          */
   float xsph_eps, st_kappa;
-  int32_t reserved[5];
+  /* 0 (default): slots inside a grid cell are ascending in particle id after every neighbour build, so
+   * every neighbour sum runs in a fixed order and results are reproducible bit for bit from run to run
+   * (and, in DSL_MATH_EXACT, equal to the reference's sums taken cell by cell).  1: keep the order the
+   * counting sort's atomics produce (saves the ordering pass of the scatter; last-bit differences between runs). */
+  int32_t sort_unordered;
+  int32_t reserved[4];
 } dsl_params;
 
 /* Counters the reference keeps on the host (fluid.go:25-26,186-191) plus the PCISPH loop
