@@ -62,6 +62,50 @@ void dslo_vec_cross3(const float a[3], const float b[3], float out[3]) {
   out[2] = a[0] * b[1] - b[0] * a[1];
 }
 
+/* vector.go:167-179 Add: the zero 3-vector when either operand is empty or the lengths differ (the
+ * rule that collapses sph.Init's lattice for a zero-length origin); n_out = length of
+ * the result. */
+int dslo_vec_add(const float *a, int na, const float *b, int nb, float *out) {
+  if (na == 0 || na != nb) {
+    out[0] = out[1] = out[2] = 0.0f;
+    return 3;
+  }
+  for (int i = 0; i < nb; i++) out[i] = a[i] + b[i];
+  return nb;
+}
+/* vector.go:232-241 Scale */
+int dslo_vec_scale(const float *a, int na, float k, float *out) {
+  if (na == 0) {
+    out[0] = out[1] = out[2] = 0.0f;
+    return 3;
+  }
+  for (int i = 0; i < na; i++) out[i] = a[i] * k;
+  return na;
+}
+/* vector.go:199-207 Sub(b, a) = Add(b, Scale(a, -1)) */
+int dslo_vec_sub(const float *b, int nb, const float *a, int na, float *out) {
+  if (na == 0 || na != nb) {
+    out[0] = out[1] = out[2] = 0.0f;
+    return 3;
+  }
+  float t[16];
+  int n = dslo_vec_scale(a, na > 16 ? 16 : na, -1.0f, t);
+  return dslo_vec_add(b, nb > 16 ? 16 : nb, t, n, out);
+}
+/* vector.go:349-353 Proj(a, n) = Scale(Norm(n), Dot(a, n) / Mag(n)) (pinned by math_test.go:90-98) */
+void dslo_vec_proj3(const float a[3], const float n[3], float out[3]) {
+  float vn[3];
+  dslo_vec_norm3(n, vn);
+  float k = dslo_vec_dot3(a, n) / dslo_vec_mag(n, 3);
+  dslo_vec_scale(vn, 3, k, out);
+}
+/* vector.go:382-385 Refl(v, n) = Sub(v, Scale(n, Dot(v, n) * 2)) (pinned by math_test.go:100-106) */
+void dslo_vec_refl3(const float v[3], const float n[3], float out[3]) {
+  float b[3];
+  dslo_vec_scale(n, 3, dslo_vec_dot3(v, n) * 2.0f, b);
+  dslo_vec_sub(v, 3, b, 3, out);
+}
+
 /* =====================================================================================
  * K: kernel/std_kernel.go
  * ===================================================================================== */

@@ -154,6 +154,11 @@ float dslo_vec_dist3(const float a[3], const float b[3]);
 float dslo_vec_dot3(const float a[3], const float b[3]);
 void dslo_vec_norm3(const float a[3], float out[3]);
 void dslo_vec_cross3(const float a[3], const float b[3], float out[3]);
+int dslo_vec_add(const float *a, int na, const float *b, int nb, float *out);   /* returns the result's length */
+int dslo_vec_scale(const float *a, int na, float k, float *out);
+int dslo_vec_sub(const float *b, int nb, const float *a, int na, float *out);
+void dslo_vec_proj3(const float a[3], const float n[3], float out[3]);
+void dslo_vec_refl3(const float v[3], const float n[3], float out[3]);
 
 /* ---- P: model/particle_array.go -------------------------------------------------- */
 int dslo_particles_init(dslo_particles *p, int n, int nb, float density, float mass);

@@ -106,6 +106,11 @@ def lib() -> C.CDLL:
         "dslo_vec_dot3": (C.c_float, [fp, fp]),
         "dslo_vec_norm3": (None, [fp, fp]),
         "dslo_vec_cross3": (None, [fp, fp, fp]),
+        "dslo_vec_add": (C.c_int, [fp, C.c_int, fp, C.c_int, fp]),
+        "dslo_vec_scale": (C.c_int, [fp, C.c_int, C.c_float, fp]),
+        "dslo_vec_sub": (C.c_int, [fp, C.c_int, fp, C.c_int, fp]),
+        "dslo_vec_proj3": (None, [fp, fp, fp]),
+        "dslo_vec_refl3": (None, [fp, fp, fp]),
         "dslo_lsh_size": (C.c_int, [C.c_int, C.c_int]),
         "dslo_lattice_positions": (None, [C.c_int, fp, C.c_int, fp]),
         "dslo_params_reference": (Params, [C.c_int]),

@@ -37,6 +37,42 @@ def test_vector_dot_and_cross_match_reference_test():
     assert np.array_equal(out, _v(2, 0, -2))
 
 
+def test_vector_add_scale_match_reference_test():
+    """math_test.go:13-24 Add({1,1,1},{1,1,1}) == {2,2,2}; :66 Scale({2,2,2}, 2) == {4,4,4};
+    :69 Add({2,2,2},{2,2,2}) == {4,4,4}"""
+    L = po.lib()
+    out = np.zeros(3, dtype=f32)
+    assert L.dslo_vec_add(_p(_v(1, 1, 1)), 3, _p(_v(1, 1, 1)), 3, _p(out)) == 3
+    assert np.array_equal(out, _v(2, 2, 2))
+    assert L.dslo_vec_scale(_p(_v(2, 2, 2)), 3, f32(2.0), _p(out)) == 3
+    assert np.array_equal(out, _v(4, 4, 4))
+    assert L.dslo_vec_add(_p(_v(2, 2, 2)), 3, _p(_v(2, 2, 2)), 3, _p(out)) == 3
+    assert np.array_equal(out, _v(4, 4, 4))
+
+
+def test_vector_add_of_an_empty_vector_is_the_zero_vector():
+    """vector.go:167-173 (and math_test.go:58-64: Vec{} is not {0,0,0}): the rule behind the collapsed
+    lattice of sph.Init(1.0, Vec{}, ...)"""
+    L = po.lib()
+    out = np.ones(3, dtype=f32)
+    empty = np.zeros(1, dtype=f32)
+    assert L.dslo_vec_add(_p(empty), 0, _p(_v(1, 2, 3)), 3, _p(out)) == 3
+    assert np.array_equal(out, _v(0, 0, 0))
+    out[:] = 1
+    assert L.dslo_vec_sub(_p(_v(1, 2, 3)), 3, _p(empty), 0, _p(out)) == 3
+    assert np.array_equal(out, _v(0, 0, 0))
+
+
+def test_vector_proj_and_refl_match_reference_test():
+    """math_test.go:86-98 Proj({2,2,0},{0,2,0}) == {0,2,0}; :100-106 Refl({1,-1,0},{0,1,0}) == {1,1,0}"""
+    L = po.lib()
+    out = np.zeros(3, dtype=f32)
+    L.dslo_vec_proj3(_p(_v(2, 2, 0)), _p(_v(0, 2, 0)), _p(out))
+    assert np.array_equal(out, _v(0, 2, 0))
+    L.dslo_vec_refl3(_p(_v(1, -1, 0)), _p(_v(0, 1, 0)), _p(out))
+    assert np.array_equal(out, _v(1, 1, 0))
+
+
 def test_vector_norm_of_zero_is_zero():
     """vector.go:322-331"""
     L = po.lib()
