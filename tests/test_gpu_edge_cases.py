@@ -122,11 +122,18 @@ def test_tile_overflow_falls_back():
     _compare_steps(p, pos, vel, 2, 2e-5, 5e-3, before=crowded)
 
 
+def _probe_sets(x, lo, hi, h):
+    inside = np.nonzero(np.all((x >= lo) & (x < hi), axis=1))[0]
+    near = np.nonzero(np.all((x >= lo - 2 * h) & (x < hi + 2 * h), axis=1))[0]
+    return inside, near
+
+
 def test_full_size_16m_properties():
-    """BASELINE full size (n3 = 252, 16,003,008 particles), FAST math, 3 steps: checked through
-    size-independent properties -- the slot map stays a permutation, cell_start is a valid
-    prefix table of the sorted cells, and the densities of every particle inside a probe box
-    equal a brute-force float64 evaluation of the reference formula on the downloaded state."""
+    """BASELINE full size (n3 = 252, 16,003,008 particles), FAST math: checked through
+    size-independent properties -- the slot map stays a permutation, cell_start is a valid prefix
+    table of the sorted cells, and for every particle inside a probe box the density AND the result of
+    the fused force+integrate kernel (new position and velocity) equal a brute-force float64
+    evaluation of the reference formulas on the downloaded state (helpers.brute_force_step_f64)."""
     from dieselfluid_amd import SPHEngine, scenes
     n3 = 252
     p, pos = scenes.dambreak_scene(n3, math_mode=FAST)
@@ -145,28 +152,49 @@ def test_full_size_16m_properties():
     assert seen.all(), "slot -> particle map must be a permutation"
     cs = eng.download_cell_start()
     assert cs[0] == 0 and cs[-1] == n and np.all(np.diff(cs) >= 0)
+    cell_of_slot = np.repeat(np.arange(cs.size - 1), np.diff(cs))
+    assert np.all(np.diff(ids)[cell_of_slot[1:] == cell_of_slot[:-1]] > 0), "cells must be ordered by particle id"
+    del cell_of_slot, seen
     st = eng.stats()
     assert np.diff(cs).max() == st.max_cell_count
     x = eng.download("positions")
+    v = eng.download("velocities")
     rho = eng.download("densities")
     assert np.isfinite(x).all() and np.isfinite(rho).all()
-    # probe box in the bulk of the block; candidates from the box dilated by h
     h = np.float32(p.h)
-    lo, hi = np.array([0.40, 0.30, 0.45], np.float32), np.array([0.40, 0.30, 0.45], np.float32) + 6 * h
-    inside = np.all((x >= lo) & (x < hi), axis=1)
-    near = np.all((x >= lo - h) & (x < hi + h), axis=1)
-    xi, xn = x[inside].astype(np.float64), x[near].astype(np.float64)
-    assert 500 < xi.shape[0] < 5000
-    A = 315.0 / (64.0 * 3.141592653589 * float(h) ** 3)
-    want = np.empty(xi.shape[0])
-    for k in range(xi.shape[0]):
-        d2 = ((xn - xi[k]) ** 2).sum(axis=1)
-        m = (d2 < float(h) ** 2) & (d2 > 0)
-        want[k] = float(p.mass) * A * ((1.0 - d2[m] / float(h) ** 2) ** 2).sum()
-    assert helpers.rel_err(rho[inside], want) < 2e-5
+    # probe box at the free surface corner of the block (the part of the fluid that is moving)
+    lo = np.array([0.90, 0.90, 0.45], np.float32)
+    inside, near = _probe_sets(x, lo, lo + 5 * h, h)
+    assert 300 < inside.shape[0] < 5000
+    want_rho, want_x, want_v = helpers.brute_force_step_f64(p, x, v, inside, near)
+    assert helpers.rel_err(rho[inside], want_rho) < 2e-5
+    eng.force_pass()  # the fused pressure + viscosity + integrate + walls kernel on exactly this state
+    x1, v1 = eng.download("positions"), eng.download("velocities")
+    assert np.isfinite(x1).all() and np.isfinite(v1).all()
+    # (a) against the float64 brute force: displacement and velocity change of this one step.  The
+    # pressure sum is ill-conditioned in float32 (pair terms ~100x the net force, EOS exponent 7.16 on a
+    # density known to 1e-6), so float32 and float64 differ by a few 1e-4 of the largest change in the box.
+    dx_want, dx_got = want_x - x[inside].astype(np.float64), x1[inside].astype(np.float64) - x[inside].astype(np.float64)
+    assert np.abs(dx_got - dx_want).max() < 1e-3 * np.abs(dx_want).max() + 2e-7 * np.abs(want_x).max()
+    dv_want, dv_got = want_v - v[inside].astype(np.float64), v1[inside].astype(np.float64) - v[inside].astype(np.float64)
+    assert np.abs(dv_got - dv_want).max() < 1e-3 * np.abs(dv_want).max()
+    # (b) against the float32 oracle: the particles within 2h of the box, taken out of the 16M state
+    # in ascending id, ARE the complete neighbourhood of every probe particle and of each of its
+    # neighbours, so one oracle step of that subset gives the probe particles what a 16M-particle oracle
+    # run would -- at the FAST tolerances of the small-scale parity tests.
+    order = near  # (np.nonzero is ascending and host order is id order)
+    frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (order.shape[0], 1))
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), x[order], vel=v[order], force=frc)
+    ora.wcsph_step(1)
+    sel = np.searchsorted(order, inside)
+    ox, ov = ora.positions()[sel], ora.velocities()[sel]
+    assert np.abs(x1[inside].astype(np.float64) - ox).max() < 1e-6 * np.abs(ox).max()
+    dv_ora = ov.astype(np.float64) - v[inside].astype(np.float64)
+    assert np.abs(dv_got - dv_ora).max() < helpers.fast_velocity_tolerance(p, 1)  # (measured: 0.13 of the model bound)
     # Update resets every force and pressure after a step (fluid.go:192-193)
+    assert st.steps == 3 and eng.stats().steps == 3
     eng.wcsph_step(1)
-    assert st.steps == 3 and eng.stats().steps == 4
+    assert eng.stats().steps == 4
 
 
 def test_shared_short_passes_match_the_oracle():
