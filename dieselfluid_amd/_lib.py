@@ -108,6 +108,19 @@ EXPORTS = {
     "dsl_slab_status": (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int]),
     "dsl_slab_overflow": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dsl_get_count": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dsl_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "dsl_comm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(_vp)]),
+    "dsl_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "dsl_comm_destroy": (C.c_int, [_vp]),
+    "dsl_comm_last_error": (C.c_char_p, []),
+    "dsl_create_multi": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(_vp)]),
+    "dsl_slab_attach": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
+    "dsl_slab_detach": (C.c_int, [_vp]),
+    "dsl_slab_image_shift": (C.c_int, [_vp, C.c_float, C.c_float]),
+    "dsl_slab_exchange": (C.c_int, [_vp]),
+    "dsl_slab_replan": (C.c_int, [_vp]),
+    "dsl_slab_wcsph_step": (C.c_int, [_vp, C.c_int]),
+    "dsl_slab_pcisph_step": (C.c_int, [_vp, C.c_int]),
     "dsl_set_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_reset_forces": (C.c_int, [_vp]),
     "dsl_last_error": (C.c_char_p, [_vp]),

@@ -29,6 +29,8 @@
 #include "kernels_lsh.hpp"
 #include "kernels_tiled.hpp"
 
+struct SlabLink;
+
 using namespace dsl;
 
 namespace {
@@ -59,13 +61,6 @@ struct dsl_handle {
   int *bucket_of = nullptr, *lsh_table = nullptr, *lsh_len = nullptr, *lsh_samples = nullptr;
   TileGrid tg{};
   int *tiles = nullptr, *n_tiles = nullptr;
-  // tile statistics the density kernel leaves in host-mapped memory, never waited for: [0] non-empty
-  // tiles, [1] tiles with a short last pass, [2] sequence number -> which instantiation of the tiled
-  // kernels the next launches use
-  volatile int* host_tstats = nullptr;
-  int* dev_tstats = nullptr;
-  int tstats_seq = 0, tstats_seen = 0;
-  bool share_short = false;
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -87,6 +82,7 @@ struct dsl_handle {
   bool grid_valid = false, forces_uniform = false, press_zero = true, pci_active = false, dens_fresh = false;
   int64_t steps = 0;
   std::string err;
+  SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
   int timing = 0;  // 0 off, 1 every kernel, 2 the step's dominant kernels only
   std::vector<hipEvent_t> pool;
@@ -416,30 +412,18 @@ int persistent_grid(const dsl_handle* h, int blocks_per_cu) {
   return g < 8 ? 8 : g;
 }
 
-// Short passes (kernels_tiled.hpp: for_each_target) are shared out by a second copy of the sweep
-// that costs a few per cent where every tile holds exactly one full pass (a lattice at rest).
-// Which instantiation runs follows the tile statistics of the latest neighbour build whose
-// read-back has arrived; it is never waited for.
-void poll_tile_stats(dsl_handle* h) {
-  if (!h->host_tstats) return;
-  const int seq = h->host_tstats[2];
-  if (seq == h->tstats_seen) return;
-  h->tstats_seen = seq;
-  h->share_short = (long long)h->host_tstats[1] * 12 > (long long)h->host_tstats[0];
-}
-
 int density_pass(dsl_handle* h) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
   if (h->prm.math_mode == DSL_MATH_FAST) {
-    poll_tile_stats(h);
+    // both instantiations are launched; the one the tile statistics of this build do not ask for
+    // returns at once (kernels_tiled.hpp: share_wanted)
     int rc = timed(h, DSL_K_DENSITY, [&] {
-      const int seq = ++h->tstats_seq;
 #define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
   hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, \
-                     h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap, h->dev_tstats, seq)
-      if (h->share_short) DSL_LAUNCH_DENSITY(k_density_tiled<true>);
-      else DSL_LAUNCH_DENSITY(k_density_tiled<false>);
+                     h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap)
+      DSL_LAUNCH_DENSITY(k_density_tiled<false>);
+      DSL_LAUNCH_DENSITY(k_density_tiled<true>);
 #undef DSL_LAUNCH_DENSITY
     });
     if (rc) return rc;
@@ -483,7 +467,6 @@ int force_integrate(dsl_handle* h, int part = 0) {
   const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
   int rc = DSL_OK;
   if (use_tiled(h)) {
-    poll_tile_stats(h);
     rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
       int gsz = persistent_grid(h, 2);
       // Two of these workgroups fill a CU's vector registers, and a persistent grid keeps them
@@ -496,11 +479,16 @@ int force_integrate(dsl_handle* h, int part = 0) {
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
-                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap)
+                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, (XX) ? nullptr : h->n_tiles)
+  // (the XSPH / cohesion variant exists as the pass-sharing instantiation only; of the other two
+  // the device picks: kernels_tiled.hpp, share_wanted)
 #define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                        \
   do {                                                                        \
-    if (XX || h->share_short) DSL_LAUNCH_FT4(GG, VV, XX, SS, true);           \
-    else DSL_LAUNCH_FT4(GG, VV, false, SS, false);                            \
+    if (XX) DSL_LAUNCH_FT4(GG, VV, XX, SS, true);                             \
+    else {                                                                    \
+      DSL_LAUNCH_FT4(GG, VV, false, SS, false);                               \
+      DSL_LAUNCH_FT4(GG, VV, false, SS, true);                                \
+    }                                                                         \
   } while (0)
 #define DSL_LAUNCH_FT2(GG, VV, XX)                     \
   do {                                                \
@@ -671,7 +659,6 @@ void free_all(dsl_handle* h) {
       (void)hipEventDestroy(pr.second);
     }
   if (h->ev_band) (void)hipEventDestroy(h->ev_band);
-  if (h->host_tstats) (void)hipHostFree(const_cast<int*>(h->host_tstats));
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -688,6 +675,8 @@ int alloc_pci(dsl_handle* h) {
 }
 
 }  // namespace
+
+#include "slab_link.hpp"
 
 extern "C" {
 
@@ -808,16 +797,6 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
   if (h->prm.math_mode == DSL_MATH_FAST && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
-  if (h->prm.math_mode == DSL_MATH_FAST) {
-    int* hp = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&hp), 8 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer(reinterpret_cast<void**>(&h->dev_tstats), hp, 0) != hipSuccess) {
-      h->err = "tile statistics buffer";
-      return bail(DSL_ERR_DEVICE);
-    }
-    for (int k = 0; k < 8; ++k) hp[k] = 0;
-    h->host_tstats = hp;
-  }
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
   for (int k = 0; k < 6 && me == hipSuccess; ++k) me = hipMemsetAsync(h->pv[0][k], 0, n * sizeof(float), h->stream);
@@ -860,6 +839,7 @@ int dsl_destroy(dsl_handle* h) {
                  d[0], d[1], d[10], d[8], d[9], d[11], d[2], d[3], d[4], d[5], d[12], d[13], d[6]);
   }
 #endif
+  (void)dsl_slab_detach(h);
   free_all(h);
   delete h;
   return DSL_OK;
@@ -1306,17 +1286,17 @@ int pci_begin_step(dsl_handle* h) {
       if (XS)
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr);
       else
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr);
     });
     if (rc) return rc;
     rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
       hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
                          dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                         h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap);
+                         h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr);
     });
     if (rc) return rc;
   } else {
@@ -1586,8 +1566,8 @@ int dsl_force_pass_split(dsl_handle* h, int phase) {
   return fail(h, DSL_ERR_INVALID, "dsl_force_pass_split: bad phase");
 }
 
-int dsl_slab_append2(dsl_handle* h, const float* dev_message_a, const float* dev_message_b, int cap_full,
-                     int cap_xonly) {
+static int slab_append_shifted(dsl_handle* h, const float* dev_message_a, const float* dev_message_b, int cap_full,
+                               int cap_xonly, float shift_a, float shift_b) {
   CHECK_HANDLE(h);
   if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_append: no slab configured");
   if ((!dev_message_a && !dev_message_b) || cap_full < 0 || cap_xonly < 0)
@@ -1604,13 +1584,18 @@ int dsl_slab_append2(dsl_handle* h, const float* dev_message_a, const float* dev
   }
   hipLaunchKernelGGL(k_slab_append, dim3(grid_for(cap_full + cap_xonly), 2), dim3(kBlock), 0, h->stream, dev_message_a,
                      dev_message_b, cap_full, cap_xonly, h->dn, h->cap, p.x, p.y, p.z, v.x, v.y, v.z,
-                     h->ids[h->cur_ids], h->dn + 5, dsl_slab_record_floats(h), pcip, pciv);
+                     h->ids[h->cur_ids], h->dn + 5, dsl_slab_record_floats(h), pcip, pciv, h->c.slab_axis, shift_a, shift_b);
   hipLaunchKernelGGL(k_slab_bump, dim3(1), dim3(1), 0, h->stream, dev_message_a, dev_message_b, cap_full, cap_xonly,
                      h->dn, h->cap);
   HIP_TRY(h, hipGetLastError());
   h->grid_valid = false;
   h->dens_fresh = false;
   return DSL_OK;
+}
+
+int dsl_slab_append2(dsl_handle* h, const float* dev_message_a, const float* dev_message_b, int cap_full,
+                     int cap_xonly) {
+  return slab_append_shifted(h, dev_message_a, dev_message_b, cap_full, cap_xonly, 0.0f, 0.0f);
 }
 
 int dsl_slab_append(dsl_handle* h, const float* dev_message, int cap_full, int cap_xonly) {
@@ -1658,6 +1643,333 @@ int dsl_slab_overflow(dsl_handle* h, int* high_water) {
   int32_t st[4] = {0, 0, 0, 0};
   if (int rc = dsl_slab_status(h, st, 0)) return rc;
   if (high_water) *high_water = st[0];
+  return DSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// multi-GPU behind the C ABI: communicator, slab link, step drivers (slab_link.hpp)
+// ---------------------------------------------------------------------------------------
+const char* dsl_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int dsl_comm_unique_id(uint8_t id[DSL_COMM_ID_BYTES]) {
+  if (!id) return DSL_ERR_INVALID;
+  if (!rccl_load()) {
+    g_comm_error = rccl().err;
+    return DSL_ERR_UNSUPPORTED;
+  }
+  static_assert(DSL_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId u;
+  const ncclResult_t r = rccl().GetUniqueId(&u);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r);
+    return DSL_ERR_DEVICE;
+  }
+  std::memcpy(id, u.internal, DSL_COMM_ID_BYTES);
+  return DSL_OK;
+}
+
+int dsl_comm_create(int nranks, int rank, const uint8_t id[DSL_COMM_ID_BYTES], int device, dsl_comm** out) {
+  if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) {
+    g_comm_error = "dsl_comm_create: bad argument";
+    return DSL_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (!rccl_load()) {
+    g_comm_error = rccl().err;
+    return DSL_ERR_UNSUPPORTED;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    g_comm_error = "dsl_comm_create: hipSetDevice failed";
+    return DSL_ERR_DEVICE;
+  }
+  ncclUniqueId u;
+  std::memcpy(u.internal, id, DSL_COMM_ID_BYTES);
+  dsl_comm* c = new (std::nothrow) dsl_comm();
+  if (!c) return DSL_ERR_NOMEM;
+  const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r);
+    delete c;
+    return DSL_ERR_DEVICE;
+  }
+  c->nranks = nranks;
+  c->rank = rank;
+  c->device = device;
+  *out = c;
+  return DSL_OK;
+}
+
+int dsl_comm_create_all(int ndev, const int* devices, dsl_comm** out) {
+  if (!out || !devices || ndev < 1) {
+    g_comm_error = "dsl_comm_create_all: bad argument";
+    return DSL_ERR_INVALID;
+  }
+  if (!rccl_load()) {
+    g_comm_error = rccl().err;
+    return DSL_ERR_UNSUPPORTED;
+  }
+  std::vector<ncclComm_t> comms((size_t)ndev);
+  const ncclResult_t r = rccl().CommInitAll(comms.data(), ndev, devices);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclCommInitAll: ") + rccl().GetErrorString(r);
+    return DSL_ERR_DEVICE;
+  }
+  for (int k = 0; k < ndev; ++k) {
+    dsl_comm* c = new dsl_comm();
+    c->comm = comms[(size_t)k];
+    c->nranks = ndev;
+    c->rank = k;
+    c->device = devices[k];
+    out[k] = c;
+  }
+  return DSL_OK;
+}
+
+int dsl_comm_destroy(dsl_comm* c) {
+  if (!c) return DSL_OK;
+  if (c->comm && rccl().lib) (void)rccl().CommDestroy(c->comm);
+  delete c;
+  return DSL_OK;
+}
+
+int dsl_create_multi(const dsl_params* params, int ndev, const int* devices, dsl_handle** handles, dsl_comm** comms) {
+  if (!params || !devices || !handles || !comms || ndev < 1) return fail(nullptr, DSL_ERR_INVALID, "dsl_create_multi: bad argument");
+  for (int k = 0; k < ndev; ++k) handles[k] = nullptr, comms[k] = nullptr;
+  for (int k = 0; k < ndev; ++k) {
+    if (int rc = dsl_create(&params[k], devices[k], &handles[k])) {
+      for (int j = 0; j < k; ++j) (void)dsl_destroy(handles[j]), handles[j] = nullptr;
+      return rc;
+    }
+  }
+  if (int rc = dsl_comm_create_all(ndev, devices, comms)) {
+    for (int j = 0; j < ndev; ++j) (void)dsl_destroy(handles[j]), handles[j] = nullptr;
+    return fail(nullptr, rc, g_comm_error);
+  }
+  return DSL_OK;
+}
+
+int dsl_slab_detach(dsl_handle* h) {
+  if (!h || !h->link) return DSL_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  SlabLink* L = h->link;
+  if (L->comm_stream) (void)hipStreamSynchronize(L->comm_stream);
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(L->send[k]);
+    (void)hipFree(L->recv[k]);
+  }
+  (void)hipFree(L->dev_words);
+  if (L->ev_pack) (void)hipEventDestroy(L->ev_pack);
+  if (L->ev_xfer) (void)hipEventDestroy(L->ev_xfer);
+  if (L->comm_stream) (void)hipStreamDestroy(L->comm_stream);
+  delete L;
+  h->link = nullptr;
+  return DSL_OK;
+}
+
+int dsl_slab_attach(dsl_handle* h, dsl_comm* comm, int lo_rank, int hi_rank, float width_full, float width, int cap_full,
+                    int cap_xonly, int overlap) {
+  CHECK_HANDLE(h);
+  if (!h->c.n_ptr) return fail(h, DSL_ERR_INVALID, "dsl_slab_attach: call dsl_slab_config first");
+  if ((lo_rank >= 0 || hi_rank >= 0) && !comm) return fail(h, DSL_ERR_INVALID, "dsl_slab_attach: neighbours need a communicator");
+  if (comm && (lo_rank >= comm->nranks || hi_rank >= comm->nranks))
+    return fail(h, DSL_ERR_INVALID, "dsl_slab_attach: neighbour rank outside the communicator");
+  if (cap_full < 0 || cap_xonly < 0 || !(width_full >= 0.0f) || !(width >= width_full))
+    return fail(h, DSL_ERR_INVALID, "dsl_slab_attach: bad widths or capacities");
+  if (overlap && !use_tiled(h)) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_slab_attach: the split step needs DSL_MATH_FAST");
+  (void)dsl_slab_detach(h);
+  SlabLink* L = new (std::nothrow) SlabLink();
+  if (!L) return fail(h, DSL_ERR_NOMEM, "dsl_slab_attach: out of host memory");
+  h->link = L;
+  L->comm = comm;
+  L->lo = lo_rank;
+  L->hi = hi_rank;
+  L->width_full = width_full;
+  L->width = width;
+  L->cap_full = cap_full;
+  L->cap_x = cap_xonly;
+  L->max_full = 2 * cap_full;  // room for the re-plan to grow the messages (the same on every rank)
+  L->max_x = 2 * cap_xonly;
+  L->overlap = overlap != 0 && (lo_rank >= 0 || hi_rank >= 0);
+  L->buf_floats = (size_t)(L->max_full + 1) * kRecordPci + (size_t)L->max_x * kRecordX;  // (13-float records once PCISPH runs)
+  for (int k = 0; k < 2; ++k) {
+    if (int rc = dev_alloc(h, &L->send[k], L->buf_floats)) return rc;
+    if (int rc = dev_alloc(h, &L->recv[k], L->buf_floats)) return rc;
+    HIP_TRY(h, hipMemsetAsync(L->send[k], 0, L->buf_floats * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(L->recv[k], 0, L->buf_floats * sizeof(float), h->stream));
+  }
+  if (int rc = dev_alloc(h, &L->dev_words, 4)) return rc;
+  HIP_TRY(h, hipStreamCreateWithFlags(&L->comm_stream, hipStreamNonBlocking));
+  HIP_TRY(h, hipEventCreateWithFlags(&L->ev_pack, hipEventDisableTiming));
+  HIP_TRY(h, hipEventCreateWithFlags(&L->ev_xfer, hipEventDisableTiming));
+  if (L->overlap) {
+    if (int rc = dsl_slab_split(h, width, h->split_margin > 0.0f ? h->split_margin : width)) return rc;
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return DSL_OK;
+}
+
+namespace {
+// one fixed-size message per neighbour and direction, all four transfers in one RCCL group
+int link_post(dsl_handle* h, hipStream_t st) {
+  SlabLink& L = *h->link;
+  if (L.lo < 0 && L.hi < 0) return DSL_OK;
+  RcclApi& a = rccl();
+  const size_t n = dsl_slab_message_floats_for(h, L.cap_full, L.cap_x);
+  ncclComm_t comm = L.comm->comm;
+  NCCL_TRY_H(h, a.GroupStart());
+  if (L.lo >= 0) NCCL_TRY_H(h, a.Send(L.send[0], n, ncclFloat, L.lo, comm, st));
+  if (L.hi >= 0) NCCL_TRY_H(h, a.Send(L.send[1], n, ncclFloat, L.hi, comm, st));
+  // two messages between the same pair of ranks (two ranks with periodic images, or a rank that is
+  // its own neighbour in a test) are matched in issue order: the peer's LOW band arrives from above
+  const bool same_peer = L.lo >= 0 && L.lo == L.hi;
+  if (same_peer) {
+    NCCL_TRY_H(h, a.Recv(L.recv[1], n, ncclFloat, L.hi, comm, st));
+    NCCL_TRY_H(h, a.Recv(L.recv[0], n, ncclFloat, L.lo, comm, st));
+  } else {
+    if (L.lo >= 0) NCCL_TRY_H(h, a.Recv(L.recv[0], n, ncclFloat, L.lo, comm, st));
+    if (L.hi >= 0) NCCL_TRY_H(h, a.Recv(L.recv[1], n, ncclFloat, L.hi, comm, st));
+  }
+  NCCL_TRY_H(h, a.GroupEnd());
+  return DSL_OK;
+}
+
+int link_append(dsl_handle* h) {
+  SlabLink& L = *h->link;
+  if (L.lo < 0 && L.hi < 0) return DSL_OK;
+  if (int rc = slab_append_shifted(h, L.lo >= 0 ? L.recv[0] : nullptr, L.hi >= 0 ? L.recv[1] : nullptr, L.cap_full, L.cap_x,
+                                   L.shift_from_lo, L.shift_from_hi))
+    return rc;
+  L.ghosts_in = true;
+  return DSL_OK;
+}
+
+// unsplit exchange on the handle's stream: pack, transfer, append
+int link_exchange(dsl_handle* h) {
+  SlabLink& L = *h->link;
+  if (L.lo < 0 && L.hi < 0) return DSL_OK;
+  if (int rc = slab_pack_on(h, h->stream, L.width_full, L.width, false, L.lo >= 0 ? L.send[0] : nullptr,
+                            L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x))
+    return rc;
+  if (int rc = link_post(h, h->stream)) return rc;
+  return link_append(h);
+}
+
+// every rank learns the largest band counts (and any overflow) seen anywhere since the last
+// re-plan; all ranks switch to the same new message capacities.  Blocking.
+int link_replan(dsl_handle* h) {
+  SlabLink& L = *h->link;
+  int32_t st[4] = {0, 0, 0, 0};
+  if (int rc = dsl_slab_status(h, st, 1)) return rc;
+  if (L.comm && L.comm->nranks > 1) {
+    HIP_TRY(h, hipMemcpyAsync(L.dev_words, st, sizeof(st), hipMemcpyHostToDevice, h->stream));
+    NCCL_TRY_H(h, rccl().AllReduce(L.dev_words, L.dev_words, 4, ncclInt32, ncclMax, L.comm->comm, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(st, L.dev_words, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  if (st[0] != 0)
+    return fail(h, DSL_ERR_OVERFLOW,
+                "slab exchange overflow: " + std::to_string(st[0]) +
+                    " records did not fit a band message or the particle capacity on some rank; particles were lost -- "
+                    "enlarge cap_full / cap_xonly / dsl_params.capacity");
+  if (st[1] != 0)
+    return fail(h, DSL_ERR_OVERFLOW, "split slab step: a particle outran the margin on some rank (ghosts were missed); enlarge the margin");
+  const long long want_full = (long long)(1.15 * st[2]) + 1024, want_x = (long long)(1.15 * st[3]) + 1024;
+  L.cap_full = (int)(want_full < L.max_full ? want_full : L.max_full);
+  L.cap_x = (int)(want_x < L.max_x ? want_x : L.max_x);
+  return DSL_OK;
+}
+}  // namespace
+
+int dsl_slab_image_shift(dsl_handle* h, float from_lo, float from_hi) {
+  CHECK_HANDLE(h);
+  if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_image_shift: call dsl_slab_attach first");
+  h->link->shift_from_lo = from_lo;
+  h->link->shift_from_hi = from_hi;
+  return DSL_OK;
+}
+
+int dsl_slab_exchange(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_exchange: call dsl_slab_attach first");
+  if (h->split_pending) return fail(h, DSL_ERR_INVALID, "dsl_slab_exchange: a split force pass is in flight");
+  return link_exchange(h);
+}
+
+int dsl_slab_replan(dsl_handle* h) {
+  CHECK_HANDLE(h);
+  if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_replan: call dsl_slab_attach first");
+  return link_replan(h);
+}
+
+int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
+  CHECK_HANDLE(h);
+  if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_wcsph_step: call dsl_slab_attach first");
+  SlabLink& L = *h->link;
+  const bool alone = L.lo < 0 && L.hi < 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (!L.ghosts_in)
+      if (int rc = link_exchange(h)) return rc;  // first step: migrants + 2h ghosts from both neighbours
+    if (int rc = build_grid(h, false)) return rc;  // counting sort; drops the previous step's ghosts
+    if (int rc = density_pass(h)) return rc;        // owned + ghosts
+    L.ghosts_in = false;
+    if (alone || !L.overlap) {
+      if (int rc = force_integrate(h)) return rc;  // owned only; ghosts are marked for removal
+      if (int rc = link_exchange(h)) return rc;
+    } else {
+      // band layers first; their pack and the RCCL transfer (side stream) run under the interior launch
+      if (!h->ev_band) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_band, hipEventDisableTiming));
+      if (int rc = force_integrate(h, 1)) return rc;
+      h->split_pending = true;
+      if (int rc = slab_pack_on(h, h->stream, L.width_full, h->split_width, true, L.lo >= 0 ? L.send[0] : nullptr,
+                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x))
+        return rc;
+      HIP_TRY(h, hipEventRecord(L.ev_pack, h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(L.comm_stream, L.ev_pack, 0));
+      if (int rc = link_post(h, L.comm_stream)) return rc;
+      HIP_TRY(h, hipEventRecord(L.ev_xfer, L.comm_stream));
+      h->split_pending = false;
+      if (int rc = force_integrate(h, 2)) return rc;
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, L.ev_xfer, 0));
+      if (int rc = link_append(h)) return rc;
+    }
+    h->steps++;
+    L.steps++;
+    if (!alone && L.steps % L.replan_every == 0)
+      if (int rc = link_replan(h)) return rc;
+  }
+  return DSL_OK;
+}
+
+int dsl_slab_pcisph_step(dsl_handle* h, int nsteps) {
+  CHECK_HANDLE(h);
+  if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_pcisph_step: call dsl_slab_attach first");
+  if (!h->pci_active) return fail(h, DSL_ERR_INVALID, "dsl_slab_pcisph_step: call dsl_pcisph_begin first");
+  SlabLink& L = *h->link;
+  const bool alone = L.lo < 0 && L.hi < 0;
+  const bool reduce = L.comm && L.comm->nranks > 1;
+  for (int s = 0; s < nsteps; ++s) {
+    if (!L.ghosts_in)
+      if (int rc = link_exchange(h)) return rc;
+    L.ghosts_in = false;
+    h->pci_split_guard = true;
+    if (int rc = pci_begin_step(h)) return rc;
+    for (int it = 0; it < h->prm.pci_max_iters; ++it) {
+      if (int rc = pci_iterate(h)) return rc;
+      // the early-out of pcisph_darwin.go:95-98 is decided by the maximum over all ranks: the error
+      // word holds a non-negative float, whose bits order like an unsigned integer
+      if (reduce)
+        NCCL_TRY_H(h, rccl().AllReduce(&h->dstats->pci_cur_err_bits, &h->dstats->pci_cur_err_bits, 1, ncclUint32, ncclMax,
+                                        L.comm->comm, h->stream));
+      if (int rc = pci_check(h)) return rc;
+    }
+    h->pci_split_guard = false;
+    if (int rc = pci_end_step(h)) return rc;  // Update; ghosts are marked for removal
+    if (int rc = link_exchange(h)) return rc;
+    L.steps++;
+    if (!alone && L.steps % L.replan_every == 0)
+      if (int rc = link_replan(h)) return rc;
+  }
   return DSL_OK;
 }
 

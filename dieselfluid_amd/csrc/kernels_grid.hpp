@@ -533,8 +533,11 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
                                                         float* __restrict__ pz, float* __restrict__ vx,
                                                         float* __restrict__ vy, float* __restrict__ vz,
                                                         int* __restrict__ ids, int* __restrict__ slab_state, int rec,
-                                                        Soa3 pcip, Soa3 pciv) {
+                                                        Soa3 pcip, Soa3 pciv, int axis, float shift0, float shift1) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
+  // periodic images: the records of message 0 / 1 are moved by shift0 / shift1 along the slab axis
+  const float sh = blockIdx.y == 0 ? shift0 : shift1;
+  const float shx = axis == 0 ? sh : 0.f, shy = axis == 1 ? sh : 0.f, shz = axis == 2 ? sh : 0.f;
   int nf0 = 0, nx0 = 0, nf1 = 0, nx1 = 0;
   if (msg0) slab_counts(msg0, cap_full, cap_x, nf0, nx0);
   if (msg1) slab_counts(msg1, cap_full, cap_x, nf1, nx1);
@@ -550,17 +553,17 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
   if (k < nf) {
     const float* r = msg + (size_t)(k + 1) * rec;
     const int d = at + k;
-    px[d] = r[0];
-    py[d] = r[1];
-    pz[d] = r[2];
+    px[d] = r[0] + shx;
+    py[d] = r[1] + shy;
+    pz[d] = r[2] + shz;
     vx[d] = r[3];
     vy[d] = r[4];
     vz[d] = r[5];
     ids[d] = __float_as_int(r[6]);
     if (rec == kRecordPci) {  // a migrant keeps its predictor state (the reference never re-synchronises it)
-      pcip.x[d] = r[7];
-      pcip.y[d] = r[8];
-      pcip.z[d] = r[9];
+      pcip.x[d] = r[7] + shx;
+      pcip.y[d] = r[8] + shy;
+      pcip.z[d] = r[9] + shz;
       pciv.x[d] = r[10];
       pciv.y[d] = r[11];
       pciv.z[d] = r[12];
@@ -569,17 +572,17 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
     const int j = k - cap_full;
     const float* r = msg + (size_t)(cap_full + 1) * rec + (size_t)j * kRecordX;
     const int d = at + nf + j;
-    px[d] = r[0];
-    py[d] = r[1];
-    pz[d] = r[2];
+    px[d] = r[0] + shx;
+    py[d] = r[1] + shy;
+    pz[d] = r[2] + shz;
     vx[d] = 0.f;
     vy[d] = 0.f;
     vz[d] = 0.f;
     ids[d] = -2 - (int)(blockIdx.y * cap_x + j);  // negative = position-only ghost; distinct: the sort orders a cell by id
     if (rec == kRecordPci) {  // ghosts: never predicted, any finite value will do
-      pcip.x[d] = r[0];
-      pcip.y[d] = r[1];
-      pcip.z[d] = r[2];
+      pcip.x[d] = r[0] + shx;
+      pcip.y[d] = r[1] + shy;
+      pcip.z[d] = r[2] + shz;
       pciv.x[d] = 0.f;
       pciv.y[d] = 0.f;
       pciv.z[d] = 0.f;

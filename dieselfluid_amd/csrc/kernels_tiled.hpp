@@ -356,6 +356,17 @@ __device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane,
   DSL_STAMP_ADD(NF == 8 ? 9 : 13, s1, s2);  // staging: wait for the data + LDS writes
 }
 
+// Which instantiation of the tiled kernels sweeps this neighbour build: the one that shares short
+// passes out (SHARE) when more than one tile in twelve has a short last pass, else the plain one.  The
+// host launches BOTH; each reads the tile statistics k_tile_list left on the device and the one that is
+// not wanted returns at once (~4 us).  (The host used to choose from statistics it polled in mapped
+// memory without waiting: which launch saw which build's statistics depended on timing, and the two
+// instantiations round differently -- results varied from run to run.)
+// stats = the tile-list counters: [0] non-empty tiles, [5] tiles with a short last pass; nullptr = always run
+__device__ __forceinline__ bool share_wanted(const int* __restrict__ stats) {
+  return (long long)stats[5] * 12 > (long long)stats[0];
+}
+
 // Passes over a tile's targets (see k_density_tiled).  Full passes: one lane per target,
 // body(false_type, t, 0, 1), lanes permuted for conflict-free ds_read_b128.  When at most half a
 // block of targets is left, k = 2, 4, 8 or 16 adjacent lanes share each target:
@@ -397,8 +408,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
                                                           const int* __restrict__ n_tiles,
                                                           const int* __restrict__ cell_start, CSoa3 p,
                                                           float* __restrict__ rho, float* __restrict__ pterm,
-                                                          unsigned int* __restrict__ nmask, int mstride,
-                                                          volatile int* __restrict__ host_stats, int stats_seq) {
+                                                          unsigned int* __restrict__ nmask, int mstride) {
   // Tiles are pipelined across the loop: while tile T is swept, the records of tile T+1 are on their
   // way from HBM into registers (15 per lane) and the row table of tile T+2 likewise (7 per lane), so a
   // tile's set-up and staging cost two barriers and some LDS writes instead of two memory round trips
@@ -406,14 +416,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
-  // tile statistics of this neighbour build, written straight into host-mapped memory for the
-  // host to find whenever it next looks (it picks the kernel instantiations from them)
-  if (host_stats != nullptr && blockIdx.x == 0 && tid == 0) {
-    host_stats[0] = n_tiles[0];
-    host_stats[1] = n_tiles[5];
-    __threadfence_system();
-    host_stats[2] = stats_seq;
-  }
+  if (share_wanted(n_tiles) != SHARE) return;  // (n_tiles is the base of the tile-list counters here)
   auto load_rec = [&](int g, float* o) {
     o[0] = p.x[g];
     o[1] = p.y[g];
@@ -591,7 +594,8 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
-    const unsigned int* __restrict__ nmask, int mstride) {
+    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats) {
+  if (share_stats != nullptr && share_wanted(share_stats) != SHARE) return;
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];  // x,y,z,P/rho^2
   __shared__ float4 B[kTCap];  // vx,vy,vz,1/rho

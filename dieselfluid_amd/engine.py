@@ -38,6 +38,40 @@ def reference_params(n3: int) -> Params:
     return p
 
 
+class Comm:
+    """dsl_comm: the RCCL communicator libdslsph.so owns (include/dslsph.h).  Rank 0 makes the unique id,
+    the host hands its 128 bytes to every rank (here: any callable `bcast(bytes_or_None) -> bytes`)."""
+
+    def __init__(self, nranks: int, rank: int, device: int, bcast=None):
+        self._L = load_library()
+        self.ptr = C.c_void_p()
+        self.nranks, self.rank = int(nranks), int(rank)
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            rc = self._L.dsl_comm_unique_id(ident)
+            if rc:
+                raise DslError(f"dsl_comm_unique_id failed ({rc}): {self._L.dsl_comm_last_error().decode()}")
+        if nranks > 1:
+            if bcast is None:
+                raise DslError("Comm: nranks > 1 needs a broadcast function for the unique id")
+            raw = bcast(bytes(ident) if rank == 0 else None)
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        rc = self._L.dsl_comm_create(self.nranks, self.rank, ident, int(device), C.byref(self.ptr))
+        if rc:
+            raise DslError(f"dsl_comm_create failed ({rc}): {self._L.dsl_comm_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self._L.dsl_comm_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SPHEngine:
     def __init__(self, params: Params, device: int = 0):
         self._L = load_library()
@@ -185,6 +219,33 @@ class SPHEngine:
         v = C.c_int(0)
         self._ck(self._L.dsl_slab_overflow(self._h, C.byref(v)))
         return v.value
+
+    # -- the exchange behind the C ABI (RCCL inside libdslsph.so) ---------------------------------
+    def slab_attach(self, comm, lo_rank: int, hi_rank: int, width_full: float, width: float, cap_full: int,
+                    cap_xonly: int, overlap: bool):
+        """comm: a Comm (or None for a lone slab); neighbour ranks, -1 at a domain end"""
+        self._comm = comm  # keep it alive as long as the link
+        self._ck(self._L.dsl_slab_attach(self._h, comm.ptr if comm is not None else None, int(lo_rank), int(hi_rank),
+                                         C.c_float(width_full), C.c_float(width), int(cap_full), int(cap_xonly),
+                                         1 if overlap else 0))
+
+    def slab_detach(self):
+        self._ck(self._L.dsl_slab_detach(self._h))
+
+    def slab_image_shift(self, from_lo: float, from_hi: float):
+        self._ck(self._L.dsl_slab_image_shift(self._h, C.c_float(from_lo), C.c_float(from_hi)))
+
+    def slab_exchange(self):
+        self._ck(self._L.dsl_slab_exchange(self._h))
+
+    def slab_replan(self):
+        self._ck(self._L.dsl_slab_replan(self._h))
+
+    def slab_wcsph_step(self, nsteps: int = 1):
+        self._ck(self._L.dsl_slab_wcsph_step(self._h, int(nsteps)))
+
+    def slab_pcisph_step(self, nsteps: int = 1):
+        self._ck(self._L.dsl_slab_pcisph_step(self._h, int(nsteps)))
 
     def download_ids(self) -> np.ndarray:
         out = np.empty(self.n, dtype=np.int32)

@@ -25,7 +25,13 @@ import torch
 import torch.distributed as dist
 
 from . import scenes
+from ._lib import DslError
 from .engine import SPHEngine
+
+
+class SlabOverflow(DslError):
+    """a band message, the particle capacity or the split margin was outgrown on some rank: particles or
+    ghosts were lost, the run is no longer valid"""
 
 RECORD = 7    # full record: x,y,z,vx,vy,vz,id-bits
 RECORD_X = 3  # position-only record
@@ -213,12 +219,51 @@ class SlabDriver:
         """message sizes follow the band occupancy: every rank learns the largest counts seen
         anywhere since the last re-plan and all switch to the same new capacities"""
         st = self.engine.status(reset_high_water=True)
-        hw = torch.tensor([st[2], st[3]], dtype=torch.int64, device=self.comm_dev)
+        hw = torch.tensor([st[0], st[1], st[2], st[3]], dtype=torch.int64, device=self.comm_dev)
         dist.all_reduce(hw, op=dist.ReduceOp.MAX, group=self.group)
-        hw_full, hw_x = (int(v) for v in hw.cpu())
-        self.engine.set_caps(int(1.15 * hw_full) + 1024, int(1.15 * hw_x) + 1024)
+        overflow, missed, hw_full, hw_x = (int(v) for v in hw.cpu())
+        # every rank sees the same reduced words, so every rank raises (or none does)
+        if overflow:
+            raise SlabOverflow(f"slab exchange overflow: {overflow} records did not fit a band message or the particle "
+                               "capacity on some rank; particles were lost (enlarge cap_full / cap_x / capacity)")
+        if missed:
+            raise SlabOverflow("split slab step: a particle outran the margin on some rank; ghosts were missed")
+        want_full, want_x = int(1.15 * hw_full) + 1024, int(1.15 * hw_x) + 1024
+        max_full, max_x = getattr(self.engine, "max_full", want_full), getattr(self.engine, "max_x", want_x)
+        if hw_full > max_full or hw_x > max_x:
+            raise SlabOverflow(f"band occupancy ({hw_full} full, {hw_x} position-only records) outgrew the message "
+                               f"buffers ({max_full}, {max_x})")
+        self.engine.set_caps(want_full, want_x)
+
+    # -- the exchange behind the C ABI (dsl_slab_attach & co.: RCCL inside libdslsph.so) --------
+    def attach_native(self, comm=None, lo_rank=None, hi_rank=None):
+        """Hands the whole slab step to the library: the RCCL group send/recv, the split step, the
+        re-plan.  This driver is then a thin caller (wcsph_step / pcisph_step are one C call each)."""
+        from .engine import Comm
+        core = self.engine_core
+        if comm is None and self.world > 1:
+            def bcast(raw):
+                objs = [raw]
+                dist.broadcast_object_list(objs, src=0, group=self.group)
+                return objs[0]
+            comm = Comm(self.world, self.rank, core.device, bcast)
+        lo_nb, hi_nb = self._neighbours()
+        if lo_rank is not None or hi_rank is not None:  # (tests: a rank that is its own periodic neighbour)
+            lo_nb, hi_nb = lo_rank, hi_rank
+        core.use_own_stream()  # the library orders its own streams; nothing of torch's is involved any more
+        core.slab_attach(comm, -1 if lo_nb is None else lo_nb, -1 if hi_nb is None else hi_nb, self.width_full,
+                         self.width, self.engine.cap_full, self.engine.cap_x, self.overlap)
+        self.native = True
+        return comm
 
     def wcsph_step(self, nsteps: int = 1):
+        if getattr(self, "native", False):
+            try:
+                self.engine_core.slab_wcsph_step(nsteps)
+            except DslError as e:
+                raise SlabOverflow(str(e)) if "overflow" in str(e) or "margin" in str(e) else e
+            self.steps += nsteps
+            return
         e = self.engine
         lo_nb, hi_nb = self._neighbours()
         for _ in range(nsteps):
@@ -250,6 +295,13 @@ class SlabDriver:
         has to be global is the iteration's max density error (the early-out of
         pcisph_darwin.go:95-98), one 4-byte MAX all-reduce per iteration.  Migrants carry their
         predictor state in the message (13-float records)."""
+        if getattr(self, "native", False):
+            try:
+                self.engine_core.slab_pcisph_step(nsteps)
+            except DslError as e:
+                raise SlabOverflow(str(e)) if "overflow" in str(e) or "margin" in str(e) else e
+            self.steps += nsteps
+            return
         e = self.engine
         core = self.engine_core
         iters = int(core.params.pci_max_iters)
@@ -301,7 +353,7 @@ class SlabDriver:
     @classmethod
     def dambreak(cls, n3: int, math_mode: int = 1, device: int = 0, axis: int = 2, rank=None, world=None,
                  engine_factory=None, group=None, vel_fn=None, overlap=None, tile_align=True, params_hook=None,
-                 pcisph=False, **scene_kw):
+                 pcisph=False, native=None, **scene_kw):
         """Dam-break of n3^3 particles split into `world` slabs along `axis` (default z: the
         collapse is symmetric in z, so the slabs stay balanced without re-planning)."""
         rank = dist.get_rank(group) if rank is None else rank
@@ -362,6 +414,12 @@ class SlabDriver:
             engine.split(width, margin)
         drv.params = p
         drv.n_total = n3 ** 3
+        # real GPUs, one per rank: the library drives the step, RCCL included.  (gloo rehearsals and the
+        # CPU logic tests keep the Python protocol above: RCCL refuses several ranks on one device.)
+        if native is None:
+            native = drv.backend == "nccl" and engine_factory is None
+        if native:
+            drv.attach_native()
         return drv
 
     @property

@@ -32,7 +32,8 @@ enum {
   DSL_ERR_INVALID = -1,  /* bad argument / bad state            */
   DSL_ERR_DEVICE = -2,   /* HIP runtime error                   */
   DSL_ERR_NOMEM = -3,    /* host or device allocation failure   */
-  DSL_ERR_UNSUPPORTED = -4
+  DSL_ERR_UNSUPPORTED = -4,
+  DSL_ERR_OVERFLOW = -5  /* slab exchange: a band message, the particle capacity or the split margin was outgrown */
 };
 
 /* Named device buffers; the names are the ones the reference registers in
@@ -324,6 +325,53 @@ int dsl_slab_append2(dsl_handle *h, const float *dev_message_a, const float *dev
 int dsl_slab_status(dsl_handle *h, int32_t status[4], int reset_high_water);
 int dsl_slab_overflow(dsl_handle *h, int *high_water);
 int dsl_get_count(dsl_handle *h, int *n_live, int *n_owned); /* blocking */
+/* ---- multi-GPU: the exchange itself, behind the C ABI --------------------------------
+ * The reference's only device host is Go (pcisph_gpu_darwin.go:249-286 drives one OpenCL queue); for
+ * it to run N > 1 GPUs the halo exchange cannot live in some other language's runtime.  These entry
+ * points own an RCCL communicator (bound at run time with dlopen: a single-GPU host never loads
+ * RCCL) and drive the whole slab step, transfers included.
+ *
+ * dsl_comm_unique_id / dsl_comm_create : ncclGetUniqueId on one rank, its 128 bytes handed to every
+ *                      rank by whatever channel the host owns (a Go channel, a socket, an MPI or
+ *                      torch.distributed broadcast), then ncclCommInitRank; one process per GPU.
+ * dsl_comm_create_all / dsl_create_multi : one process, `ndev` devices: ncclCommInitAll, resp. ndev
+ *                      handles plus their communicators.  RCCL then wants ONE HOST THREAD PER DEVICE for
+ *                      the step drivers below (a goroutine under runtime.LockOSThread each).
+ * dsl_slab_attach    : after dsl_slab_config: neighbour ranks (-1 at a domain end), band widths,
+ *                      message capacities (they may grow to twice these; identical on every rank),
+ *                      overlap = 1 for the split step.  Allocates the message buffers and the
+ *                      transfer stream.
+ * dsl_slab_exchange  : pack both bands, ncclGroupStart / ncclSend + ncclRecv per neighbour /
+ *                      ncclGroupEnd, append.  Asynchronous.
+ * dsl_slab_wcsph_step / dsl_slab_pcisph_step : the slab step, nsteps times: exchange for the next
+ *                      step at the end of each step (with overlap: band layers first, their pack and
+ *                      the transfer on a side stream under the interior force launch); PCISPH adds
+ *                      one 4-byte MAX all-reduce of the iteration error per correction iteration.
+ *                      Every 8th step the band high-water marks of all ranks are MAX-reduced (one
+ *                      host synchronisation) and every rank switches to the same new message
+ *                      sizes; an overflow or an outrun split margin ANYWHERE makes the call fail with
+ *                      DSL_ERR_OVERFLOW on every rank instead of silently losing particles.
+ * dsl_slab_replan    : that re-plan on demand (blocking, collective). */
+#define DSL_COMM_ID_BYTES 128
+typedef struct dsl_comm dsl_comm;
+int dsl_comm_unique_id(uint8_t id[DSL_COMM_ID_BYTES]);
+int dsl_comm_create(int nranks, int rank, const uint8_t id[DSL_COMM_ID_BYTES], int device, dsl_comm **out);
+int dsl_comm_create_all(int ndev, const int *devices, dsl_comm **out /* ndev */);
+int dsl_comm_destroy(dsl_comm *c);
+const char *dsl_comm_last_error(void);
+int dsl_create_multi(const dsl_params *params /* ndev */, int ndev, const int *devices, dsl_handle **handles /* ndev */,
+                     dsl_comm **comms /* ndev */);
+int dsl_slab_attach(dsl_handle *h, dsl_comm *comm, int lo_rank, int hi_rank, float width_full, float width, int cap_full,
+                    int cap_xonly, int overlap);
+int dsl_slab_detach(dsl_handle *h);
+/* periodic images along the slab axis: records arriving from the lower / upper neighbour are moved by
+ * from_lo / from_hi (a ring of ranks closes with -L / +L at its two ends, 0 elsewhere) */
+int dsl_slab_image_shift(dsl_handle *h, float from_lo, float from_hi);
+int dsl_slab_exchange(dsl_handle *h);
+int dsl_slab_replan(dsl_handle *h);
+int dsl_slab_wcsph_step(dsl_handle *h, int nsteps);
+int dsl_slab_pcisph_step(dsl_handle *h, int nsteps);
+
 /* global particle ids of the current slots (host order of dsl_upload); default 0..n-1 */
 int dsl_set_ids(dsl_handle *h, const int32_t *ids, size_t count);
 /* Marks every force as equal to force_reset (the state Update leaves, fluid.go:193) */

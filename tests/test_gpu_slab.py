@@ -115,12 +115,36 @@ def test_hip_slabs_along_x_and_y(tmp_path, axis):
     assert helpers.rel_err(z["vel"], vel) < tol_v
 
 
-def test_split_step_flags_a_margin_violation(tmp_path):
-    """particles faster than margin / dt outrun the band tiles: the run must say so"""
+def _violation_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
+    torch.cuda.set_device(0)
+    from dieselfluid_amd.slab import SlabDriver, SlabOverflow
+    SlabDriver.REPLAN_EVERY = 4
+    drv = SlabDriver.dambreak(32, math_mode=1, device=0, axis=2, overlap=True,
+                              vel_fn=lambda ids, pos: 8.0 * _vel_fn(ids, pos, axis=2))
+    raised = False
+    try:
+        drv.wcsph_step(STEPS)
+    except SlabOverflow as e:
+        raised = "margin" in str(e)
+    flags = [None] * world if rank == 0 else None
+    dist.gather_object(raised, flags, dst=0)
+    if rank == 0:
+        np.savez(out, raised=np.array(flags))
+    dist.destroy_process_group()
+
+
+def test_split_step_stops_on_a_margin_violation(tmp_path):
+    """particles faster than margin / dt outrun the band tiles: EVERY rank must stop with SlabOverflow at
+    the next re-plan (the status words are MAX-reduced over the ranks), not carry on with ghosts missing"""
     out = str(tmp_path / "slab_gpu.npz")
-    mp.spawn(_worker, args=(2, _free_port(), 1, 32, True, 8.0, out), nprocs=2, join=True)
-    z = np.load(out)
-    assert np.any(z["info"][:, 3] == 1)
+    mp.spawn(_violation_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert np.all(np.load(out)["raised"])
 
 
 # ---- PCISPH across slabs (BASELINE configs[4]'s 8-GPU form) ---------------------------------
@@ -201,3 +225,91 @@ def test_pcisph_slabs_match_single_engine(tmp_path, math_mode, world, n3, extra)
     print(f"pcisph slab-vs-single x {ex:.2e} (tol {tol_x:.2e})  v {ev:.2e} (tol {tol_v:.2e})  iters {iters} err {err:.3e}")
     assert ex < tol_x
     assert ev < tol_v
+
+
+def test_native_step_driver_matches_the_python_protocol():
+    """The exchange behind the C ABI (dsl_slab_attach / dsl_slab_wcsph_step: RCCL group send/recv
+    issued by the library, split step, re-plan) against the Python protocol it replaces, on a middle
+    rank of a 4-way split whose neighbours are its own periodic images: the library sends both bands
+    through an RCCL communicator of one rank to itself (dsl_slab_image_shift moves them by the slab
+    thickness), the Python driver moves them by device copies.  Same kernels, same message contents,
+    same (id-ordered) cells: the owned states must agree bit for bit."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from slab_periodic_bench import PeriodicDriver
+    from dieselfluid_amd.engine import Comm
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        res = {}
+        for kind in ("python", "native"):
+            for overlap in (False, True):
+                drv = PeriodicDriver.dambreak(64, math_mode=1, device=0, rank=1, world=4, overlap=overlap, native=False)
+                drv.comm_dev, drv.use_nccl = torch.device("cpu"), False
+                if kind == "native":
+                    comm = Comm(1, 0, 0)
+                    drv.attach_native(comm, 0, 0)
+                    T = drv.hi - drv.lo
+                    drv.engine_core.slab_image_shift(-T, +T)
+                drv.wcsph_step(20)
+                torch.cuda.synchronize()
+                ids, pos, vel = drv.engine.owned_state(drv.axis, drv.lo, drv.hi)
+                o = np.argsort(ids)
+                st = drv.engine.status()
+                assert st[0] == 0 and st[1] == 0
+                res[(kind, overlap)] = (ids[o], pos[o], vel[o])
+                drv.engine_core.close()
+        for overlap in (False, True):
+            a, b = res[("python", overlap)], res[("native", overlap)]
+            assert np.array_equal(a[0], b[0]) and a[0].shape[0] > 60000
+            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+            assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_native_driver_reports_an_overflow_instead_of_losing_particles():
+    """a band that does not fit its message must stop the run.  Message capacities far
+    below the band occupancy: the re-plan (every 8th step, or on demand) fails with DSL_ERR_OVERFLOW."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from slab_periodic_bench import PeriodicDriver
+    from dieselfluid_amd import slab
+    from dieselfluid_amd.engine import Comm
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29592")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        drv = PeriodicDriver.dambreak(32, math_mode=1, device=0, rank=1, world=4, overlap=False, native=False)
+        drv.engine.cap_full, drv.engine.cap_x = 64, 64  # a band holds thousands
+        drv.engine.max_full, drv.engine.max_x = 128, 128
+        comm = Comm(1, 0, 0)
+        drv.attach_native(comm, 0, 0)
+        T = drv.hi - drv.lo
+        drv.engine_core.slab_image_shift(-T, +T)
+        with pytest.raises(slab.SlabOverflow):
+            drv.wcsph_step(8)
+        drv.engine_core.close()
+        # the Python protocol raises as well (slab.py: _replan)
+        drv = PeriodicDriver.dambreak(32, math_mode=1, device=0, rank=1, world=4, overlap=False, native=False)
+        drv.comm_dev, drv.use_nccl = torch.device("cpu"), False
+        drv.engine.cap_full, drv.engine.cap_x = 64, 64
+        drv.engine.max_full, drv.engine.max_x = 128, 128
+        with pytest.raises(slab.SlabOverflow):
+            drv.wcsph_step(8)
+        drv.engine_core.close()
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-replan", action="store_true", help="no message re-sizing (and so no host sync) in the timed loop")
     ap.add_argument("--dump", default="", help="write the owned state (sorted by id) to this .npz after the run")
     ap.add_argument("--nccl", action="store_true", help="send the bands through RCCL (to this same rank)")
+    ap.add_argument("--native", action="store_true",
+                    help="the library's own step driver (dsl_slab_wcsph_step): RCCL group send/recv to this same rank, "
+                         "issued from C, periodic image shift in the append kernel")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
@@ -92,7 +95,13 @@ def main():
     if not a.null_stream:
         torch.cuda.set_stream(torch.cuda.Stream())
     drv = PeriodicDriver.dambreak(a.n3, math_mode=1, device=0, rank=a.rank, world=a.world,
-                                  overlap=not a.no_overlap)
+                                  overlap=not a.no_overlap, native=False)
+    if a.native:
+        from dieselfluid_amd.engine import Comm
+        comm = Comm(1, 0, 0)
+        drv.attach_native(comm, 0, 0)
+        T = drv.hi - drv.lo
+        drv.engine_core.slab_image_shift(-T, +T)
     drv.comm_dev = torch.device("cuda", 0) if a.nccl else torch.device("cpu")
     drv.use_nccl = a.nccl
     if a.no_replan:
@@ -114,8 +123,8 @@ def main():
     stats = eng.stats()
     n_live, n_owned = eng.n, eng.n_owned()
     out = {"ms_per_step": round(dt / a.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "owned": n_owned, "live_with_ghosts": n_live,
-           "overlap": drv.overlap, "max_cell_count": stats.max_cell_count, "grid": list(stats.grid_dims), "status": st, "caps": [drv.engine.cap_full, drv.engine.cap_x],
-           "message_MB": round(drv.engine.message_floats() * 4 / 1e6, 3),
+           "overlap": drv.overlap, "driver": "native" if a.native else ("python+rccl" if a.nccl else "python+copy"), "max_cell_count": stats.max_cell_count, "grid": list(stats.grid_dims), "status": st, "caps": [drv.engine.cap_full, drv.engine.cap_x],
+           "message_MB": round(drv.engine.message_floats() * 4 / 1e6, 3) if not a.native else None,
            "kernels_ms_per_step": {k: round(eng.timing(k)[0] * eng.timing(k)[1] / a.steps, 4) for k in
                                    ("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")},
            "ideal_ms_at_1gpu_rate": None}
