@@ -44,6 +44,10 @@ def parse():
                     help="BASELINE configs[4]: add the build-defined XSPH + cohesion (surface tension) terms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the whole force pass")
+    ap.add_argument("--developed-steps", type=int, default=10000,
+                    help="N=1 WCSPH only: after the timed region advance this many steps (the column collapses, the "
+                         "lattice melts: ~10000 steps = 0.45 s of flow at n3=252) and time 20 more; reported as "
+                         "developed_ms_per_step beside the headline.  0 = skip")
     ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
     ap.add_argument("--cpu-steps", type=int, default=4)
     return ap.parse_args()
@@ -196,7 +200,15 @@ def main():
     steps_f = args.steps if events_in_region else timed_launch_steps
     if n_f > steps_f:  # split force pass: two launches per step, quote the pass
         ms_f = ms_f * n_f / steps_f
-    n_local = eng.n
+    # particles this rank integrates (ghosts take part in the sums but are not integrated)
+    n_local = eng.n if world == 1 else eng.n_owned()
+    n_live = eng.n
+    if overflow or band_missed:
+        sys.stderr.write(f"bench.py: slab exchange overflow={overflow} band_missed={band_missed}: particles or ghosts "
+                         "were lost, the measurement is void\n")
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     if args.method == "pcisph":
         ms_f = timing_of("pci_density")[0]  # dominant PCISPH kernel: predicted density, 20 B/particle
         kname, kms, kbytes = "k_pci_density", ms_f, 20
@@ -206,6 +218,34 @@ def main():
         kname, kms, kbytes = "k_density", ms_d, BYTES_DENSITY
     achieved = n_local * kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     st = eng.stats()
+    kernels_ms = {k: round(timing_of(k)[0], 4) for k in
+                  (("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")
+                   if args.method == "wcsph" else
+                   ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
+                    "pci_predict", "pci_density", "update"))}
+    developed = None
+    if world == 1 and args.method == "wcsph" and args.developed_steps > 0:
+        # the headline above is the contract's configuration (the jittered lattice: exactly 8 per cell);
+        # this is the same engine once the flow has developed
+        for e in engines:
+            e.timing_enable(False)
+        chunk = 500
+        for _ in range(args.developed_steps // chunk):
+            step(chunk)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        step(20)
+        torch.cuda.synchronize()
+        td = (time.perf_counter() - td) / 20
+        eng.timing_reset()
+        eng.timing_enable(True)
+        step(5)
+        dk = {k: round(eng.timing(k)[0], 4) for k in ("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")}
+        eng.timing_enable(False)
+        sd = eng.stats()
+        developed = {"ms_per_step": round(td * 1e3, 4), "value": round(n_total / td / 1e6, 3), "kernels_ms": dk,
+                     "after_steps": args.warmup + args.steps + timed_launch_steps + (args.developed_steps // chunk) * chunk,
+                     "max_cell_count": sd.max_cell_count, "max_vel": sd.max_vel}
     # HBM bytes per launch from the PMC counters cannot be sampled from inside this process;
     # they come from the committed rocprofv3 passes of this same command (profiles/traffic.json)
     # and are only quoted for the configuration they were measured on.
@@ -256,11 +296,7 @@ def main():
                 "pass_frac_68B": round(n_local * 68 / ((ms_d + ms_f) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if (ms_d + ms_f) > 0 else None,
             },
-            "kernels_ms": {k: round(timing_of(k)[0], 4) for k in
-                           (("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")
-                            if args.method == "wcsph" else
-                            ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
-                             "pci_predict", "pci_density", "update"))},
+            "kernels_ms": kernels_ms,
             "slab_overflow": overflow,
             "slab_band_missed": band_missed,
             "slab_overlap": bool(world > 1 and drv.overlap),
@@ -269,6 +305,10 @@ def main():
                              f"separate {timed_launch_steps}-step segment after the timed region",
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,
+            "developed": developed,
+            "n_live_rank0": n_live,
+            "slab_driver": ("native (dsl_slab_wcsph_step: RCCL inside libdslsph.so)" if world > 1 and getattr(drv, "native", False)
+                            else ("python protocol" if world > 1 else None)),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -73,7 +73,7 @@ struct dsl_handle {
   bool masks_valid = false;
   int *rank = nullptr, *cell_count = nullptr, *cell_start = nullptr, *block_sums = nullptr;
   // in-cell ordering of the counting sort (kernels_grid.hpp, k_scatter): bitmap of the cells to order,
-  // their ids at the slots the atomic ranks name, work list of their particles
+  // their ids at the slots the atomic ranks name, one byte per particle that marks their particles
   unsigned int* unordered = nullptr;
   int *sort_keys = nullptr, *sort_work = nullptr;
   float* stage = nullptr;
@@ -319,7 +319,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   rc = timed(h, DSL_K_SCAN, [&] {
     hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan, h->dstats,
-                       h->prm.math_mode == DSL_MATH_FAST ? h->n_tiles : nullptr, h->dcounter + 1);
+                       h->prm.math_mode == DSL_MATH_FAST ? h->n_tiles : nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
                        h->cell_start, h->dstats);
   });
@@ -349,7 +349,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   float* derived[3] = {(carry_derived && h->dens_fresh) ? h->rho : nullptr, (carry_derived && h->dens_fresh) ? h->pterm : nullptr,
                        (carry_derived && !h->press_zero) ? h->press : nullptr};
   const bool want_dest = derived[0] || derived[1] || derived[2];
-  ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, h->sort_work, h->dcounter + 1, want_dest ? h->rank : nullptr};
+  ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work),
+                  want_dest ? h->rank : nullptr};
   rc = timed(h, DSL_K_SCATTER, [&] {
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
     if (ordered)

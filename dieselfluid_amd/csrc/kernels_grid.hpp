@@ -121,10 +121,9 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ co
 // and everything that follows it, so it also clears the small counters of the later kernels
 // (the fullest-cell statistic of phase 3, the tile-list lengths) instead of two more memsets.
 __global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sums, int nb, DevStats* stats,
-                                                     int* __restrict__ n_tiles, int* __restrict__ n_work) {
+                                                     int* __restrict__ n_tiles) {
   __shared__ int lds[kBlock / kWave];
   if (threadIdx.x == 0) stats->max_cell_count = 0;
-  if (threadIdx.x == 0) *n_work = 0;
   if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
   int carry = 0;
   for (int base = 0; base < nb; base += kBlock) {
@@ -186,7 +185,7 @@ struct ScatterArrays {
 // atomics happened to land, different from run to run -- and with it the order of every neighbour
 // sum, i.e. the last bits of every result.  The particles of the cells k_cell_rank has marked (more
 // than one run, or a run not ascending in id) are therefore scattered in two steps: k_scatter only puts
-// their ids at the slots the atomic ranks name and their indices on a work list; k_scatter_ordered then
+// their ids at the slots the atomic ranks name and marks them; k_scatter_ordered then
 // lets every one of them count the ids of its cell that are smaller than its own and take that slot.
 // Slots inside a cell are then ascending in particle id whatever the atomics did: the order of the
 // oracle's DSLO_ORDER_CELL and, cell by cell, of the reference's bucket lists (lsh.go:113-118 appends
@@ -194,10 +193,12 @@ struct ScatterArrays {
 struct ScatterOrder {
   const unsigned int* unordered;  // bitmap from k_cell_rank; nullptr = keep the order the atomics left
   int* keys;                      // ids at the atomic slots (marked cells only)
-  int* work;                      // indices of the particles of marked cells
-  int* n_work;
+  unsigned char* later;           // per particle: 1 = belongs to a marked cell, k_scatter_ordered places it
   int* dest;                      // optional: final slot of every particle (to permute derived arrays)
 };
+// (No compacted work list: appending to one costs an atomic per wave on a single counter -- 250k
+// same-address atomics per 16M-particle build serialise in L2 and took 2.8 ms once the flow had
+// developed.  A byte per particle costs 32 MB of traffic and no atomics.)
 
 __device__ __forceinline__ void scatter_move(const ScatterArrays& a, const ScatterOrder& o, int i, int d, int id) {
   a.ids_dst[d] = id;
@@ -210,35 +211,24 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
+  if (i >= live_n(c)) return;
   bool later = false;
-  int cell = 0;
-  if (i < live_n(c)) {
-    cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
-    if (cell != c.ncell) {  // (a stale ghost is dropped)
-      const int id = a.ids_src[i];
-      const int d = cell_start[cell] + rank[i];
-      later = o.unordered != nullptr && ((o.unordered[cell >> 5] >> (cell & 31)) & 1u);
-      if (later) o.keys[d] = id;
-      else scatter_move(a, o, i, d, id);
-    }
+  const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+  if (cell != c.ncell) {  // (a stale ghost is dropped)
+    const int id = a.ids_src[i];
+    const int d = cell_start[cell] + rank[i];
+    later = o.unordered != nullptr && ((o.unordered[cell >> 5] >> (cell & 31)) & 1u);
+    if (later) o.keys[d] = id;
+    else scatter_move(a, o, i, d, id);
   }
-  const unsigned long long m = __ballot(later);  // one atomic per wave
-  if (m != 0ull) {
-    const int leader = __builtin_ctzll(m);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(o.n_work, __builtin_popcountll(m));
-    base = __shfl(base, leader, kWave);
-    if (later) o.work[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
-  }
+  if (o.unordered != nullptr) o.later[i] = later ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                             const int* __restrict__ rank,
                                                             const int* __restrict__ cell_start) {
-  const int w = blockIdx.x * kBlock + threadIdx.x;
-  if (w >= *o.n_work) return;
-  const int i = o.work[w];
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= live_n(c) || !o.later[i]) return;
   const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
   const int id = a.ids_src[i];
   const int s = cell_start[cell], e = cell_start[cell + 1], mine = s + rank[i];
