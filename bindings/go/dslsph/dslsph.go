@@ -115,6 +115,132 @@ func (e *Engine) PCISPHStep(n int) error { return e.ck(C.dsl_pcisph_step(e.h, C.
 func (e *Engine) Sync() error            { return e.ck(C.dsl_sync(e.h)) }
 func (e *Engine) SetParams() error       { return e.ck(C.dsl_set_params(e.h, &e.Params)) }
 
+// ---- boundary particles (model/particle_array.go:123-128, model/field/sph_field.go:75-85) ----
+
+// AddBoundaryParticles appends position-only particles behind the fluid (needs room in Params.capacity).
+func (e *Engine) AddBoundaryParticles(positions []float32) error {
+	if len(positions) == 0 {
+		return nil
+	}
+	return e.ck(C.dsl_add_boundary_particles(e.h, (*C.float)(unsafe.Pointer(&positions[0])), C.size_t(len(positions))))
+}
+
+// ---- the SPHField operators no solver calls (model/field/sph_field.go:124-135,203-294) ----
+
+func (e *Engine) fieldOut(n int, call func(*C.float, C.size_t) C.int) ([]float32, error) {
+	out := make([]float32, n)
+	if n == 0 {
+		return out, nil
+	}
+	return out, e.ck(call((*C.float)(unsafe.Pointer(&out[0])), C.size_t(n)))
+}
+func (e *Engine) Div(tensorBuffer C.int) ([]float32, error) {
+	return e.fieldOut(int(e.Params.n_particles), func(p *C.float, n C.size_t) C.int { return C.dsl_field_divergence(e.h, tensorBuffer, p, n) })
+}
+func (e *Engine) Curl(tensorBuffer C.int) ([]float32, error) {
+	return e.fieldOut(3*int(e.Params.n_particles), func(p *C.float, n C.size_t) C.int { return C.dsl_field_curl(e.h, tensorBuffer, p, n) })
+}
+func (e *Engine) Laplacian(scalarBuffer C.int) ([]float32, error) {
+	return e.fieldOut(int(e.Params.n_particles), func(p *C.float, n C.size_t) C.int { return C.dsl_field_laplacian(e.h, scalarBuffer, p, n) })
+}
+func (e *Engine) Interpolate(scalarBuffer C.int, positions []float32) ([]float32, error) {
+	out := make([]float32, len(positions)/3)
+	if len(out) == 0 {
+		return out, nil
+	}
+	return out, e.ck(C.dsl_field_interpolate(e.h, scalarBuffer, (*C.float)(unsafe.Pointer(&positions[0])), C.size_t(len(out)),
+		(*C.float)(unsafe.Pointer(&out[0]))))
+}
+
+// ---- render hand-off without the per-step full read-back (pcisph_gpu_darwin.go:276-282) ----
+
+// DownloadDecimated: every stride-th particle of positions / velocities.
+func (e *Engine) DownloadDecimated(buffer C.int, stride int, out []float32) error {
+	if len(out) == 0 {
+		return nil
+	}
+	return e.ck(C.dsl_download_decimated(e.h, buffer, C.int(stride), (*C.float)(unsafe.Pointer(&out[0])), C.size_t(len(out))))
+}
+
+// DevicePointers: the live SoA device arrays (x, y, z), the slot -> particle id map and the slot count.
+func (e *Engine) DevicePointers(buffer C.int) (xyz [3]unsafe.Pointer, ids unsafe.Pointer, n int, err error) {
+	var p [3]*C.float
+	var i *C.int32_t
+	var cn C.int
+	err = e.ck(C.dsl_device_pointers(e.h, buffer, (**C.float)(unsafe.Pointer(&p[0])), &i, &cn))
+	return [3]unsafe.Pointer{unsafe.Pointer(p[0]), unsafe.Pointer(p[1]), unsafe.Pointer(p[2])}, unsafe.Pointer(i), int(cn), err
+}
+
+// ---- lsh_ref parity mode (sampler/lsh/lsh.go) ----
+
+func (e *Engine) SetHashVectors(vectors []float32) error { // lsh.Allocate's random projections, bits x 3
+	return e.ck(C.dsl_set_hash_vectors(e.h, (*C.float)(unsafe.Pointer(&vectors[0])), C.int(len(vectors)/3)))
+}
+
+// ---- multi-GPU: one Engine per device, RCCL inside the library (include/dslsph.h) ----
+
+// Comm wraps dsl_comm.  Rank 0 calls CommUniqueID and hands the 128 bytes to the other ranks over any channel.
+type Comm struct{ c *C.dsl_comm }
+
+func CommUniqueID() ([128]byte, error) {
+	var id [128]byte
+	if rc := C.dsl_comm_unique_id((*C.uint8_t)(unsafe.Pointer(&id[0]))); rc != 0 {
+		return id, errors.New(C.GoString(C.dsl_comm_last_error()))
+	}
+	return id, nil
+}
+func NewComm(nranks, rank int, id [128]byte, device int) (*Comm, error) {
+	c := &Comm{}
+	if rc := C.dsl_comm_create(C.int(nranks), C.int(rank), (*C.uint8_t)(unsafe.Pointer(&id[0])), C.int(device), &c.c); rc != 0 {
+		return nil, errors.New(C.GoString(C.dsl_comm_last_error()))
+	}
+	return c, nil
+}
+func (c *Comm) Close() { C.dsl_comm_destroy(c.c); c.c = nil }
+
+// NewEngines: one process, several devices (dsl_create_multi: handles + ncclCommInitAll).  Drive each Engine
+// from its own goroutine under runtime.LockOSThread: RCCL wants one host thread per device.
+func NewEngines(params []C.dsl_params, devices []int) ([]*Engine, []*Comm, error) {
+	n := len(devices)
+	devs := make([]C.int, n)
+	for k, d := range devices {
+		devs[k] = C.int(d)
+	}
+	hs := make([]*C.dsl_handle, n)
+	cs := make([]*C.dsl_comm, n)
+	if rc := C.dsl_create_multi(&params[0], C.int(n), &devs[0], &hs[0], &cs[0]); rc != 0 {
+		return nil, nil, lastError(nil)
+	}
+	engs, comms := make([]*Engine, n), make([]*Comm, n)
+	for k := range hs {
+		engs[k], comms[k] = &Engine{h: hs[k], Params: params[k]}, &Comm{c: cs[k]}
+	}
+	return engs, comms, nil
+}
+
+// SlabConfig / SlabAttach: this engine owns [lo, hi) along axis and exchanges a 2h band with the ranks lo_rank
+// and hi_rank (-1 at a domain end) every step.
+func (e *Engine) SlabConfig(axis int, lo, hi float32) error {
+	return e.ck(C.dsl_slab_config(e.h, C.int(axis), C.float(lo), C.float(hi)))
+}
+func (e *Engine) SetIDs(ids []int32) error {
+	return e.ck(C.dsl_set_ids(e.h, (*C.int32_t)(unsafe.Pointer(&ids[0])), C.size_t(len(ids))))
+}
+func (e *Engine) SlabAttach(c *Comm, loRank, hiRank int, widthFull, width float32, capFull, capX int, overlap bool) error {
+	var cc *C.dsl_comm
+	if c != nil {
+		cc = c.c
+	}
+	ov := C.int(0)
+	if overlap {
+		ov = 1
+	}
+	return e.ck(C.dsl_slab_attach(e.h, cc, C.int(loRank), C.int(hiRank), C.float(widthFull), C.float(width), C.int(capFull), C.int(capX), ov))
+}
+func (e *Engine) SlabWCSPHStep(n int) error  { return e.ck(C.dsl_slab_wcsph_step(e.h, C.int(n))) }
+func (e *Engine) SlabPCISPHStep(n int) error { return e.ck(C.dsl_slab_pcisph_step(e.h, C.int(n))) }
+func (e *Engine) SlabReplan() error          { return e.ck(C.dsl_slab_replan(e.h)) }
+
 // MaxV: SPH.MaxV() (fluid.go:206)
 func (e *Engine) MaxV() (float32, error) {
 	var st C.dsl_stats
@@ -140,6 +266,7 @@ type ComputeGPU struct {
 	eng        *Engine
 	registered map[string]int
 	kernels    map[string]bool
+	pending    string
 	log        string
 }
 
@@ -182,9 +309,126 @@ func (cp *ComputeGPU) ReadFloatBuffer(cpu_buffer []float32, name string) error {
 	return cp.eng.Download(bufferIDs[name], cpu_buffer)
 }
 
-func (cp *ComputeGPU) PassLayoutBuffer(data interface{}, bytes int, name string) error { return nil } // gpu.go:378-390
-func (cp *ComputeGPU) AddSourceFile(filename string) error                           { return nil } // gpu.go:257-271
-func (cp *ComputeGPU) BuildProgram(include_dir string) error                         { return nil } // gpu.go:194-229
+// PassLayoutBuffer (gpu.go:378-390) carries the two parameter blocks of pcisph_gpu_darwin.go:60-61.  They
+// are not dropped: "sizes" {N, Nboundary, buckets, bucket_size} and "floats" {dt, mass, delta, maxVel, h}
+// are checked against the engine's own parameters, so a host that disagrees with the device finds out.
+func (cp *ComputeGPU) PassLayoutBuffer(data interface{}, bytes int, name string) error {
+	if !auxBuffers[name] {
+		return fmt.Errorf("buffer [%s] not registered", name)
+	}
+	p := &cp.eng.Params
+	switch v := data.(type) {
+	case []int32:
+		if name == "sizes" && len(v) >= 2 && (C.int32_t(v[0]) != p.n_particles || C.int32_t(v[1]) != p.n_boundary) {
+			return errors.New("sizes block {N, Nboundary, ..} does not match the engine's parameters")
+		}
+	case []float32:
+		if name == "floats" && len(v) >= 5 && (C.float(v[0]) != p.dt || C.float(v[1]) != p.mass || C.float(v[4]) != p.h) {
+			return errors.New("floats block {dt, mass, delta, maxVel, h} does not match the engine's parameters")
+		}
+	}
+	cp.log += "Passed Layout Buffer " + name + "\n"
+	return nil
+}
+func (cp *ComputeGPU) AddSourceFile(filename string) error   { return nil }  // gpu.go:257-271: nothing to compile
+func (cp *ComputeGPU) AddSourceString(source string) bool    { return true } // compute.go:46
+func (cp *ComputeGPU) BuildProgram(include_dir string) error { return nil }  // gpu.go:194-229
+
+// ---- the rest of compute.GPUCompute (compute/compute.go:26-53) ----
+
+// Setup (compute.go:29): the device context is the handle NewEngine made.
+func (cp *ComputeGPU) Setup(gl bool) bool { return cp.HasDeviceContext() }
+
+// Queue (gpu.go:286-296) names the built-in kernel the next Run executes.
+func (cp *ComputeGPU) Queue(name string) error {
+	if !cp.kernels[name] {
+		return fmt.Errorf("kernel [%s] not registered", name)
+	}
+	cp.pending = name
+	return nil
+}
+
+// Run (compute.go:33): the reference's two fused device kernels are phases of the PCISPH step here --
+// compute_density (pci_density.c:12-23) = NN, density, viscosity; predict_correct (pci_predict.c:9-27) = the
+// correction loop + integrate -- then THREAD_DONE (103) or THREAD_ERR (102) goes down the channel.
+func (cp *ComputeGPU) Run(x chan int) {
+	var rc C.int
+	h := cp.eng.h
+	switch cp.pending {
+	case "compute_density":
+		if rc = C.dsl_pcisph_begin(h); rc == 0 {
+			rc = C.dsl_pcisph_phase(h, C.DSL_PCI_BEGIN_STEP)
+		}
+	case "predict_correct":
+		for it := 0; rc == 0 && it < int(cp.eng.Params.pci_max_iters); it++ {
+			if rc = C.dsl_pcisph_phase(h, C.DSL_PCI_ITERATE); rc == 0 {
+				rc = C.dsl_pcisph_phase(h, C.DSL_PCI_CHECK)
+			}
+		}
+		if rc == 0 {
+			rc = C.dsl_pcisph_phase(h, C.DSL_PCI_END_STEP)
+		}
+	default:
+		rc = C.DSL_ERR_INVALID
+	}
+	if rc == 0 {
+		rc = C.dsl_sync(h)
+	}
+	if rc == 0 {
+		x <- 103
+	} else {
+		x <- 102
+	}
+}
+
+// PassIntBuffer / ReadIntBuffer (gpu.go:354-378): "sizes" is checked / returned; "sampler" (the host's
+// flattened LSH table, lsh.go:70-80) is accepted and ignored on the way in -- the engine builds its own
+// neighbour table -- and is HashSampler.GetData1D of the device table on the way out (DSL_NEIGH_LSH_REF).
+func (cp *ComputeGPU) PassIntBuffer(cpu_buffer []int, name string) error {
+	if !auxBuffers[name] {
+		return cp.isregistered(name)
+	}
+	p := &cp.eng.Params
+	if name == "sizes" && len(cpu_buffer) >= 2 && (C.int32_t(cpu_buffer[0]) != p.n_particles || C.int32_t(cpu_buffer[1]) != p.n_boundary) {
+		return errors.New("sizes block {N, Nboundary, ..} does not match the engine's parameters")
+	}
+	cp.log += "Passed Integer Buffer " + name + "\n"
+	return nil
+}
+func (cp *ComputeGPU) ReadIntBuffer(cpu_buffer []int, name string) error {
+	p := &cp.eng.Params
+	switch name {
+	case "sizes":
+		v := [4]int{int(p.n_particles), int(p.n_boundary), int(p.lsh_buckets), int(p.lsh_bucket_size)}
+		copy(cpu_buffer, v[:])
+		return nil
+	case "sampler":
+		t := make([]int32, len(cpu_buffer))
+		if len(t) == 0 {
+			return nil
+		}
+		if err := cp.eng.ck(C.dsl_lsh_download_table(cp.eng.h, (*C.int32_t)(unsafe.Pointer(&t[0])), C.size_t(len(t)))); err != nil {
+			return err
+		}
+		for k := range t {
+			cpu_buffer[k] = int(t[k])
+		}
+		return nil
+	}
+	return fmt.Errorf("buffer [%s] holds no integers", name)
+}
+
+// RegisterGLBuffer (gpu.go:323-330) shares a GL buffer with the device queue so that the renderer draws what
+// the solver wrote without a read-back.  The counterpart here goes the other way: the consumer is handed the
+// live device arrays (DevicePointers); the GL id is only recorded.
+func (cp *ComputeGPU) RegisterGLBuffer(gl_buffer_id uint32, size int, name string) error {
+	if name != "positions" {
+		return errors.New("only the positions buffer has a render hand-off")
+	}
+	cp.registered[name] = size
+	cp.log += fmt.Sprintf("RegisterGLBuffer() - buffer %s (GL id %d): read the device arrays through DevicePointers()\n", name, gl_buffer_id)
+	return nil
+}
 
 func (cp *ComputeGPU) RegisterKernel(name string) bool { // gpu.go:231-250
 	ok := name == "compute_density" || name == "predict_correct"

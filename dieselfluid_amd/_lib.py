@@ -64,6 +64,7 @@ EXPORTS = {
     "dsl_get_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "dsl_upload": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
     "dsl_download": (C.c_int, [_vp, C.c_int, _fp, C.c_size_t]),
+    "dsl_add_boundary_particles": (C.c_int, [_vp, _fp, C.c_size_t]),
     "dsl_download_decimated": (C.c_int, [_vp, C.c_int, C.c_int, _fp, C.c_size_t]),
     "dsl_device_pointers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int)]),
     "dsl_set_hash_vectors": (C.c_int, [_vp, _fp, C.c_int]),

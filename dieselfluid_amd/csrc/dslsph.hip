@@ -43,6 +43,11 @@ struct dsl_handle {
   dsl_params prm{};
   DevConsts c{};
   int n = 0, cap = 0, ncell = 0, ncell_pad = 0, nscan = 0;
+  // boundary particles (particle_array.go:123-128): ids n_fluid .. n-1.  The reference's Get() reads
+  // index == N() as the zero particle (particle_array.go:98,107), so the first boundary particle takes
+  // part in every sum AT THE ORIGIN; the device copy holds (0,0,0) for it and b0_pos what was uploaded.
+  int n_fluid = 0;
+  float b0_pos[3] = {0.f, 0.f, 0.f};
   bool ids_global = false;  // dsl_set_ids replaced the host-order map
   int* dcounter = nullptr;
   // slab mode: [0] live particle count, [1..4] band counters (lo/hi full, lo/hi position-only),
@@ -125,15 +130,14 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   if (!(p.h > 0.0f)) return fail(h, DSL_ERR_INVALID, "h must be > 0");
   if (!(p.mass > 0.0f)) return fail(h, DSL_ERR_INVALID, "mass must be > 0");
   if (p.n_particles <= 0) return fail(h, DSL_ERR_INVALID, "n_particles must be > 0");
-  if (p.n_boundary != 0)
-    return fail(h, DSL_ERR_UNSUPPORTED, "boundary particles are not supported (disabled in the reference, fluid.go:70)");
+  if (p.n_boundary < 0) return fail(h, DSL_ERR_INVALID, "n_boundary must be >= 0");
   if (p.neigh_mode != DSL_NEIGH_GRID && p.neigh_mode != DSL_NEIGH_LSH_REF) return fail(h, DSL_ERR_INVALID, "bad neigh_mode");
   if (p.neigh_mode == DSL_NEIGH_LSH_REF && p.math_mode != DSL_MATH_EXACT)
     return fail(h, DSL_ERR_UNSUPPORTED, "DSL_NEIGH_LSH_REF is a parity mode: it needs DSL_MATH_EXACT");
   if (p.neigh_mode == DSL_NEIGH_LSH_REF && (p.lsh_buckets < 1 || p.lsh_buckets > 4096))
     return fail(h, DSL_ERR_INVALID, "lsh_buckets out of range");
   if (p.math_mode != DSL_MATH_EXACT && p.math_mode != DSL_MATH_FAST) return fail(h, DSL_ERR_INVALID, "bad math_mode");
-  c.n = p.n_particles;
+  c.n = p.n_particles + p.n_boundary;  // Total(): every slot is a neighbour candidate
   const float hh = p.h;
   c.h = hh;
   c.hh = hh * hh;
@@ -181,7 +185,8 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   }
   if (ncell > (1ll << 30)) return fail(h, DSL_ERR_INVALID, "grid has more than 2^30 cells; shrink the grid box or enlarge h");
   c.ncell = (int)ncell;
-  if (p.capacity != 0 && p.capacity < p.n_particles) return fail(h, DSL_ERR_INVALID, "capacity must be >= n_particles");
+  if (p.capacity != 0 && p.capacity < p.n_particles + p.n_boundary)
+    return fail(h, DSL_ERR_INVALID, "capacity must be >= n_particles + n_boundary");
   c.slab_axis = -1;
   c.slab_lo = -INFINITY;
   c.slab_hi = INFINITY;
@@ -257,6 +262,8 @@ Soa3 mfrc(dsl_handle* h) { return {h->frc[h->cur_f][0], h->frc[h->cur_f][1], h->
 CSoa3 cfrc(dsl_handle* h) { return {h->frc[h->cur_f][0], h->frc[h->cur_f][1], h->frc[h->cur_f][2]}; }
 Soa3 mpcip(dsl_handle* h) { return {h->pci[h->cur_pci][0], h->pci[h->cur_pci][1], h->pci[h->cur_pci][2]}; }
 Soa3 mpciv(dsl_handle* h) { return {h->pci[h->cur_pci][3], h->pci[h->cur_pci][4], h->pci[h->cur_pci][5]}; }
+
+Bnd bnd_of(const dsl_handle* h) { return Bnd{h->n > h->n_fluid ? h->ids[h->cur_ids] : nullptr, h->n_fluid}; }
 
 Neigh neigh(const dsl_handle* h) {
   if (h->lsh) return Neigh{h->cell_start, h->lsh_samples, h->hashv, h->lsh_bits, h->prm.lsh_buckets};
@@ -422,7 +429,7 @@ int density_pass(dsl_handle* h) {
     int rc = timed(h, DSL_K_DENSITY, [&] {
 #define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
   hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, \
-                     h->cell_start, p, h->rho, h->pterm, h->nmask, h->cap)
+                     h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap)
       DSL_LAUNCH_DENSITY(k_density_tiled<false>);
       DSL_LAUNCH_DENSITY(k_density_tiled<true>);
 #undef DSL_LAUNCH_DENSITY
@@ -435,7 +442,7 @@ int density_pass(dsl_handle* h) {
   int rc = timed(h, DSL_K_DENSITY, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         neigh(h), p, h->rho, h->pterm);
+                         neigh(h), bnd_of(h), p, h->rho, h->pterm);
     });
   });
   if (rc) return rc;
@@ -480,7 +487,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
-                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, (XX) ? nullptr : h->n_tiles)
+                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, (XX) ? nullptr : h->n_tiles, bnd_of(h))
   // (the XSPH / cohesion variant exists as the pass-sharing instantiation only; of the other two
   // the device picks: kernels_tiled.hpp, share_wanted)
 #define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                        \
@@ -517,7 +524,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
       constexpr bool FAST = decltype(fast)::value;
       dim3 g(grid_for(launch_n(h))), b(kBlock);
 #define DSL_LAUNCH_FI(GG, VV)                                                                                    \
-  hipLaunchKernelGGL((k_force_integrate<FAST, GG, VV>), g, b, 0, h->stream, c, neigh(h), p, v, h->rho,          \
+  hipLaunchKernelGGL((k_force_integrate<FAST, GG, VV>), g, b, 0, h->stream, c, neigh(h), bnd_of(h), p, v, h->rho,          \
                      h->pterm, f, uni, po, vo, h->dstats)
       if (G && V) DSL_LAUNCH_FI(true, true);
       else if (G) DSL_LAUNCH_FI(true, false);
@@ -543,7 +550,7 @@ int gradient_pass(dsl_handle* h, int honour_done) {
   return timed(h, DSL_K_GRADIENT, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_gradient<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         neigh(h), p, h->rho, h->pterm, f, h->dstats, honour_done);
+                         neigh(h), bnd_of(h), p, h->rho, h->pterm, f, h->dstats, honour_done);
     });
   });
 }
@@ -558,7 +565,7 @@ int viscous_pass(dsl_handle* h, int with_xs = 0) {
   return timed(h, DSL_K_VISCOUS, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_viscous<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         neigh(h), p, v, h->rho, f, with_xs, xs);
+                         neigh(h), bnd_of(h), p, v, h->rho, f, with_xs, xs);
     });
   });
 }
@@ -571,7 +578,7 @@ int update_pass(dsl_handle* h, bool use_xs = false) {
   CSoa3 f = cfrc(h);
   const int uni = h->forces_uniform ? 1 : 0;
   int rc = timed(h, DSL_K_UPDATE, [&] {
-    hipLaunchKernelGGL(k_update, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c, p, v, f, uni, h->dstats,
+    hipLaunchKernelGGL(k_update, dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c, bnd_of(h), p, v, f, uni, h->dstats,
                        xs);
   });
   if (rc) return rc;
@@ -745,6 +752,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     return rc;
   }
   h->n = h->c.n;
+  h->n_fluid = params->n_particles;
   h->cap = params->capacity > 0 ? params->capacity : h->n;
   h->ncell = h->c.ncell;
   h->ncell_pad = ((h->ncell + 1 + kScanTile - 1) / kScanTile) * kScanTile;
@@ -898,8 +906,14 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_upload: bad buffer id or null pointer");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
+  // positions hold Total() particles, everything else N() (particle_array.go:18-33)
+  const bool with_boundary = h->n > h->n_fluid;
+  const int limit = (buffer == DSL_BUF_POSITIONS || !with_boundary) ? ncur : h->n_fluid;
   const size_t n = (size_t)ncur;
-  if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_upload: count does not match the buffer size");
+  if (count != (size_t)limit * bi.comps)
+    return fail(h, DSL_ERR_INVALID,
+                with_boundary ? "dsl_upload: count does not match the buffer size (positions: N + Nboundary particles, others: N)"
+                              : "dsl_upload: count does not match the buffer size");
   if (h->ids_global) return fail(h, DSL_ERR_INVALID, "dsl_upload: host order is gone after dsl_set_ids");
   HIP_TRY(h, hipMemcpyAsync(h->stage, host, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
   const int* ids = h->ids[h->cur_ids];
@@ -907,32 +921,34 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
   switch (buffer) {
     case DSL_BUF_POSITIONS: {
       Soa3 p = mpos(h, h->cur_pv);
-      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, p.x, p.y, p.z);
+      const int zero_id = with_boundary ? h->n_fluid : -1;  // Get(N()) is the zero particle (particle_array.go:98,107)
+      if (with_boundary) std::memcpy(h->b0_pos, host + (size_t)3 * h->n_fluid, sizeof(h->b0_pos));
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, p.x, p.y, p.z, limit, zero_id);
       h->grid_valid = false;
       h->masks_valid = false;
       break;
     }
     case DSL_BUF_VELOCITIES: {
       Soa3 v = mvel(h, h->cur_pv);
-      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, v.x, v.y, v.z);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, v.x, v.y, v.z, limit, -1);
       break;
     }
     case DSL_BUF_FORCES: {
       Soa3 f = mfrc(h);
-      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, f.x, f.y, f.z);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, f.x, f.y, f.z, limit, -1);
       h->forces_uniform = false;
       break;
     }
     case DSL_BUF_DENSITIES:
-      hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->rho);
+      hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->rho, limit);
       // pterm must follow an uploaded density
       by_math(h, [&](auto fast) {
-        hipLaunchKernelGGL((k_pterm<decltype(fast)::value>), g, b, 0, h->stream, h->c, h->rho, h->pterm);
+        hipLaunchKernelGGL((k_pterm<decltype(fast)::value>), g, b, 0, h->stream, h->c, bnd_of(h), h->rho, h->pterm);
       });
       h->dens_fresh = true;
       break;
     case DSL_BUF_PRESSURES:
-      hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->press);
+      hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->press, limit);
       h->press_zero = false;
       break;
     case DSL_BUF_PCI_POSITIONS:
@@ -946,12 +962,43 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
         h->pci_active = true;
       }
       Soa3 d = buffer == DSL_BUF_PCI_POSITIONS ? mpcip(h) : mpciv(h);
-      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, d.x, d.y, d.z);
+      hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, d.x, d.y, d.z, limit, -1);
       break;
     }
   }
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // host pointer is not retained (cgo rule)
+  return DSL_OK;
+}
+
+int dsl_add_boundary_particles(dsl_handle* h, const float* host_positions, size_t count) {
+  CHECK_HANDLE(h);
+  if (!host_positions || count == 0 || count % 3 != 0)
+    return fail(h, DSL_ERR_INVALID, "dsl_add_boundary_particles: count must be a positive multiple of 3");
+  if (h->c.n_ptr) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_add_boundary_particles: not available in slab mode");
+  if (h->ids_global) return fail(h, DSL_ERR_INVALID, "dsl_add_boundary_particles: particle ids were replaced (dsl_set_ids)");
+  const int nb = (int)(count / 3);
+  if ((long long)h->n + nb > h->cap)
+    return fail(h, DSL_ERR_NOMEM, "dsl_add_boundary_particles: dsl_params.capacity leaves no room (needs n_particles + all boundary particles)");
+  HIP_TRY(h, hipMemcpyAsync(h->stage, host_positions, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  const bool first = h->n == h->n_fluid;
+  if (first) std::memcpy(h->b0_pos, host_positions, sizeof(h->b0_pos));
+  Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
+  Soa3 pcip{nullptr, nullptr, nullptr}, pciv{nullptr, nullptr, nullptr};
+  if (h->pci_active) {
+    pcip = mpcip(h);
+    pciv = mpciv(h);
+  }
+  hipLaunchKernelGGL(k_append_boundary, dim3(grid_for(nb)), dim3(kBlock), 0, h->stream, nb, h->n, h->n, h->n_fluid, h->stage,
+                     p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], pcip, pciv);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->n += nb;
+  h->c.n = h->n;
+  h->prm.n_boundary += nb;
+  h->grid_valid = false;
+  h->masks_valid = false;
+  h->dens_fresh = false;
   return DSL_OK;
 }
 
@@ -961,8 +1008,14 @@ static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, i
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_download: bad buffer id or null pointer");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
-  const size_t n = (size_t)ncur;
-  if (count != n * bi.comps) return fail(h, DSL_ERR_INVALID, "dsl_download: count does not match the buffer size");
+  const bool with_boundary = h->n > h->n_fluid;
+  const int limit = (buffer == DSL_BUF_POSITIONS || !with_boundary) ? ncur : h->n_fluid;
+  if (with_boundary && sorted_order && buffer != DSL_BUF_POSITIONS)
+    return fail(h, DSL_ERR_UNSUPPORTED, "dsl_download_sorted: with boundary particles only positions have a slot-order image");
+  if (count != (size_t)limit * bi.comps)
+    return fail(h, DSL_ERR_INVALID,
+                with_boundary ? "dsl_download: count does not match the buffer size (positions: N + Nboundary particles, others: N)"
+                              : "dsl_download: count does not match the buffer size");
   if (h->ids_global && !sorted_order)
     return fail(h, DSL_ERR_INVALID, "dsl_download: host order is gone after dsl_set_ids; use dsl_download_sorted + dsl_download_ids");
   const int* ids = h->ids[h->cur_ids];
@@ -1002,6 +1055,8 @@ static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, i
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(host, h->stage, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // the positions slice itself keeps what was uploaded for particle N(); only Get() reads it as the origin
+  if (with_boundary && buffer == DSL_BUF_POSITIONS && !sorted_order) std::memcpy(host + (size_t)3 * h->n_fluid, h->b0_pos, sizeof(h->b0_pos));
   return DSL_OK;
 }
 
@@ -1106,7 +1161,7 @@ int dsl_pressure_pass(dsl_handle* h) {
   int rc = timed(h, DSL_K_PRESSURE, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_pressure<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         h->rho, h->press);
+                         bnd_of(h), h->rho, h->press);
     });
   });
   if (rc) return rc;
@@ -1149,6 +1204,7 @@ int dsl_force_pass(dsl_handle* h) {
   return force_integrate(h);
 }
 
+// *ncur = slots to launch over (Total()); the operators are evaluated for the N() fluid particles
 static int field_prepare(dsl_handle* h, int* ncur) {
   if (h->c.n_ptr) return fail(h, DSL_ERR_UNSUPPORTED, "field operators are not available in slab mode");
   if (int rc = ensure_grid(h)) return rc;
@@ -1159,7 +1215,7 @@ static int field_div_curl(dsl_handle* h, int tensor_buffer, float* host_out, siz
   CHECK_HANDLE(h);
   int n = 0;
   if (int rc = field_prepare(h, &n)) return rc;
-  if (!host_out || count != (size_t)n * (curl ? 3 : 1)) return fail(h, DSL_ERR_INVALID, "field operator: bad output size");
+  if (!host_out || count != (size_t)h->n_fluid * (curl ? 3 : 1)) return fail(h, DSL_ERR_INVALID, "field operator: bad output size");
   CSoa3 t;
   if (tensor_buffer == DSL_BUF_VELOCITIES) t = cvel(h);
   else if (tensor_buffer == DSL_BUF_FORCES) {
@@ -1173,10 +1229,10 @@ static int field_div_curl(dsl_handle* h, int tensor_buffer, float* host_out, siz
     constexpr bool F = decltype(fast)::value;
     if (curl)
       hipLaunchKernelGGL((k_field_div_curl<F, kOpCurl>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
-                         neigh(h), p, t, h->rho, out);
+                         neigh(h), bnd_of(h), p, t, h->rho, out);
     else
       hipLaunchKernelGGL((k_field_div_curl<F, kOpDiv>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
-                         neigh(h), p, t, h->rho, out);
+                         neigh(h), bnd_of(h), p, t, h->rho, out);
   });
   HIP_TRY(h, hipGetLastError());
   const int* ids = h->ids[h->cur_ids];
@@ -1204,11 +1260,11 @@ int dsl_field_laplacian(dsl_handle* h, int scalar_buffer, float* host_out, size_
   int n = 0;
   if (int rc = field_prepare(h, &n)) return rc;
   const int field = scalar_field_id(scalar_buffer);
-  if (!host_out || count != (size_t)n || field < 0) return fail(h, DSL_ERR_INVALID, "dsl_field_laplacian: bad argument");
+  if (!host_out || count != (size_t)h->n_fluid || field < 0) return fail(h, DSL_ERR_INVALID, "dsl_field_laplacian: bad argument");
   CSoa3 p = cpos(h);
   by_math(h, [&](auto fast) {
     hipLaunchKernelGGL((k_field_laplacian<decltype(fast)::value>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
-                       neigh(h), p, h->rho, field, h->scratch1);
+                       neigh(h), bnd_of(h), p, h->rho, field, h->scratch1);
   });
   hipLaunchKernelGGL(k_pack1, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, n, h->stage, h->ids[h->cur_ids], h->scratch1, 0);
   HIP_TRY(h, hipGetLastError());
@@ -1287,17 +1343,17 @@ int pci_begin_step(dsl_handle* h) {
       if (XS)
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr);
+                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
       else
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr);
+                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
     });
     if (rc) return rc;
     rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
       hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
                          dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
-                         h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr);
+                         h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
     });
     if (rc) return rc;
   } else {
@@ -1317,7 +1373,7 @@ int pci_iterate(dsl_handle* h) {
   CSoa3 cF{F.x, F.y, F.z};
   Soa3 pp = mpcip(h), pvv = mpciv(h);
   int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
-    hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, cF, pp, pvv, h->dstats);
+    hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, bnd_of(h), cF, pp, pvv, h->dstats);
   });
   if (rc) return rc;
   CSoa3 cpp{pp.x, pp.y, pp.z};
@@ -1325,10 +1381,10 @@ int pci_iterate(dsl_handle* h) {
   rc = timed(h, DSL_K_PCI_DENSITY, [&] {
     if (tiled)
       hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                         h->tiles, h->n_tiles, h->cell_start, p, cpp, h->press, h->dstats);
+                         h->tiles, h->n_tiles, h->cell_start, bnd_of(h), p, cpp, h->press, h->dstats);
     else
       by_math(h, [&](auto fast) {
-        hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), p, cpp,
+        hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), bnd_of(h), p, cpp,
                            h->press, h->dstats);
       });
   });
@@ -1402,6 +1458,7 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
   CHECK_HANDLE(h);
   if (axis < -1 || axis > 2 || !(lo < hi)) return fail(h, DSL_ERR_INVALID, "dsl_slab_config: bad axis or empty range");
   if (h->lsh) return fail(h, DSL_ERR_UNSUPPORTED, "lsh_ref buckets are angular cones through the whole domain: no slabs");
+  if (axis >= 0 && h->n > h->n_fluid) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_slab_config: boundary particles are not supported in slab mode");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
   h->c.slab_axis = axis;
@@ -1979,6 +2036,7 @@ int dsl_set_ids(dsl_handle* h, const int32_t* ids, size_t count) {
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
   if (!ids || count != (size_t)ncur) return fail(h, DSL_ERR_INVALID, "dsl_set_ids: count must equal the particle count");
+  if (h->n > h->n_fluid) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_set_ids: boundary particles are told apart by their ids");
   // ids follow the host order of dsl_upload: slot s currently holds host index cur_ids[s]
   std::vector<int> cur(count), out(count);
   HIP_TRY(h, hipMemcpyAsync(cur.data(), h->ids[h->cur_ids], count * sizeof(int), hipMemcpyDeviceToHost, h->stream));

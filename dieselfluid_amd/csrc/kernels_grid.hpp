@@ -258,21 +258,55 @@ __global__ __launch_bounds__(kBlock) void k_permute1(DevConsts c, const int* __r
 // (model/particle_array.go:5-15); the device keeps SoA in cell-sorted order with
 // ids[slot] = original particle index.
 // ---------------------------------------------------------------------------------
+// `limit`: particles in the host buffer (N() for everything but positions, which hold Total());
+// `zero_id` >= 0: that particle is stored at the origin (the reference's Get(N()), dslsph.hip)
 __global__ __launch_bounds__(kBlock) void k_unpack3(int n, const float* __restrict__ stage, const int* __restrict__ ids,
                                                     float* __restrict__ x, float* __restrict__ y,
-                                                    float* __restrict__ z) {
+                                                    float* __restrict__ z, int limit, int zero_id) {
   const int s = blockIdx.x * kBlock + threadIdx.x;
   if (s >= n) return;
   const int o = ids[s];
-  x[s] = stage[3 * o];
-  y[s] = stage[3 * o + 1];
-  z[s] = stage[3 * o + 2];
+  if (o >= limit) return;
+  const bool zero = o == zero_id;
+  x[s] = zero ? 0.0f : stage[3 * o];
+  y[s] = zero ? 0.0f : stage[3 * o + 1];
+  z[s] = zero ? 0.0f : stage[3 * o + 2];
 }
 __global__ __launch_bounds__(kBlock) void k_unpack1(int n, const float* __restrict__ stage, const int* __restrict__ ids,
-                                                    float* __restrict__ x) {
+                                                    float* __restrict__ x, int limit) {
   const int s = blockIdx.x * kBlock + threadIdx.x;
   if (s >= n) return;
-  x[s] = stage[ids[s]];
+  const int o = ids[s];
+  if (o < limit) x[s] = stage[o];
+}
+// ParticleArray.AddBoundaryParticles (particle_array.go:123-128): nb position-only particles behind the
+// current ones, ids first_id .., velocity 0
+__global__ __launch_bounds__(kBlock) void k_append_boundary(int nb, int at, int first_id, int zero_id,
+                                                            const float* __restrict__ stage, float* __restrict__ x,
+                                                            float* __restrict__ y, float* __restrict__ z,
+                                                            float* __restrict__ vx, float* __restrict__ vy,
+                                                            float* __restrict__ vz, int* __restrict__ ids, Soa3 pcip,
+                                                            Soa3 pciv) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= nb) return;
+  const int d = at + k;
+  const bool zero = first_id + k == zero_id;
+  const float px = zero ? 0.0f : stage[3 * k], py = zero ? 0.0f : stage[3 * k + 1], pz = zero ? 0.0f : stage[3 * k + 2];
+  x[d] = px;
+  y[d] = py;
+  z[d] = pz;
+  vx[d] = 0.0f;
+  vy[d] = 0.0f;
+  vz[d] = 0.0f;
+  ids[d] = first_id + k;
+  if (pcip.x != nullptr) {
+    pcip.x[d] = px;
+    pcip.y[d] = py;
+    pcip.z[d] = pz;
+    pciv.x[d] = 0.0f;
+    pciv.y[d] = 0.0f;
+    pciv.z[d] = 0.0f;
+  }
 }
 __global__ __launch_bounds__(kBlock) void k_pack3(int n, float* __restrict__ stage, const int* __restrict__ ids,
                                                   const float* __restrict__ x, const float* __restrict__ y,

@@ -15,10 +15,15 @@ namespace dsl {
 // field_types.go:39-42) so the force sweep does not call pow per neighbour.
 // ---------------------------------------------------------------------------------
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_density(DevConsts c, Neigh nb, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_density(DevConsts c, Neigh nb, Bnd bnd, CSoa3 p,
                                                     float* __restrict__ rho, float* __restrict__ pterm) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
+  if (bnd.is(i)) {  // Get(): density 0, PressureField.Value(0)/0^2 = 0/0 (field_types.go:39-42)
+    rho[i] = 0.0f;
+    pterm[i] = __uint_as_float(0x7fc00000u);
+    return;
+  }
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   float density = 0.0f;
   for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
@@ -45,19 +50,21 @@ __global__ __launch_bounds__(kBlock) void k_density(DevConsts c, Neigh nb, CSoa3
 
 // PR: SPH.PressureAll (fluid.go:134-142): Press = TaitEos(rho, D0, 0)
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_pressure(DevConsts c, const float* __restrict__ rho,
+__global__ __launch_bounds__(kBlock) void k_pressure(DevConsts c, Bnd bnd, const float* __restrict__ rho,
                                                      float* __restrict__ press) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
+  if (bnd.is(i)) return;  // PressureAll loops over N() particles (fluid.go:134-142)
   press[i] = tait_eos<FAST>(c, rho[i], c.ref_density);
 }
 
 // P(rho)/rho^2 for densities that arrive by upload instead of from k_density
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_pterm(DevConsts c, const float* __restrict__ rho,
+__global__ __launch_bounds__(kBlock) void k_pterm(DevConsts c, Bnd bnd, const float* __restrict__ rho,
                                                   float* __restrict__ pterm) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
+  if (bnd.is(i)) return;
   const float d = rho[i];
   pterm[i] = dsl_div<FAST>(tait_eos<FAST>(c, d, c.eos_d0_grad), d * d);
 }
@@ -178,12 +185,12 @@ __device__ __forceinline__ void force_sweep(const DevConsts& c, Neigh nb, int i,
 
 // G: SPH.GradientPressureForce (fluid.go:164-172): F_i += sign * rho_i*m * accG
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, Neigh nb, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, Neigh nb, Bnd bnd, CSoa3 p,
                                                      const float* __restrict__ rho, const float* __restrict__ pterm,
                                                      Soa3 f, const DevStats* stats, int honour_done) {
   if (honour_done && stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  if (i >= live_n(c) || bnd.is(i)) return;  // GradientPressureForce loops over N() particles (fluid.go:164-172)
   float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f};
   CSoa3 nov{nullptr, nullptr, nullptr};
   force_sweep<FAST, true, false>(c, nb, i, p, nov, rho, pterm, accG, accV);
@@ -199,10 +206,10 @@ __global__ __launch_bounds__(kBlock) void k_gradient(DevConsts c, Neigh nb, CSoa
 // with_xs (PCISPH with the build-defined terms): the same sweep also adds the cohesion force and
 // stores the XSPH correction for Update
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, Neigh nb, CSoa3 p, CSoa3 v,
+__global__ __launch_bounds__(kBlock) void k_viscous(DevConsts c, Neigh nb, Bnd bnd, CSoa3 p, CSoa3 v,
                                                     const float* __restrict__ rho, Soa3 f, int with_xs, Soa3 xsph) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  if (i >= live_n(c) || bnd.is(i)) return;  // ViscousAll loops over N() particles (fluid.go:146-152)
   float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f}, accX[3] = {0.f, 0.f, 0.f}, accS[3] = {0.f, 0.f, 0.f};
   force_sweep<FAST, false, true>(c, nb, i, p, v, rho, nullptr, accG, accV, with_xs ? accX : nullptr,
                                  with_xs ? accS : nullptr);
@@ -285,12 +292,12 @@ __device__ __forceinline__ void integrate_one(const DevConsts& c, float fx, floa
 }
 
 // stand-alone Update: in place (per-particle, no neighbour reads)
-__global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, CSoa3 f, int forces_uniform,
+__global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Bnd bnd, Soa3 p, Soa3 v, CSoa3 f, int forces_uniform,
                                                    DevStats* stats, CSoa3 xsph) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   float fx = c.reset[0], fy = c.reset[1], fz = c.reset[2];
   float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-  const bool live = i < live_n(c);
+  const bool live = i < live_n(c) && !bnd.is(i);  // Update loops over N() particles (fluid.go:175-197)
   if (live) {
     if (!forces_uniform) {
       fx = f.x[i];
@@ -337,14 +344,15 @@ __global__ __launch_bounds__(kBlock) void k_update(DevConsts c, Soa3 p, Soa3 v, 
 // overwritten by Update (Press = 0, fluid.go:192) so it is not materialised.
 // ---------------------------------------------------------------------------------
 template <bool FAST, bool WANT_G, bool WANT_V>
-__global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh nb, CSoa3 pin,
+__global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh nb, Bnd bnd, CSoa3 pin,
                                                             CSoa3 vin, const float* __restrict__ rho,
                                                             const float* __restrict__ pterm, CSoa3 fin,
                                                             int forces_uniform, Soa3 pout, Soa3 vout,
                                                             DevStats* stats) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   const bool live = i < live_n(c);
-  const bool owned = live && slab_owned(c, pin.x[i], pin.y[i], pin.z[i]);
+  const bool boundary = live && bnd.is(i);  // carried over unchanged into the other half of the ping-pong pair
+  const bool owned = live && !boundary && slab_owned(c, pin.x[i], pin.y[i], pin.z[i]);
   float fx = 0.f, fy = 0.f, fz = 0.f, px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
   float accX[3] = {0.f, 0.f, 0.f}, accS[3] = {0.f, 0.f, 0.f};
   if (owned) {
@@ -402,9 +410,9 @@ __global__ __launch_bounds__(kBlock) void k_force_integrate(DevConsts c, Neigh n
     vout.z[i] = vz;
   } else if (live) {
     const float qnan = __uint_as_float(0x7fc00000u);  // ghost: dropped at the next neighbour build
-    pout.x[i] = qnan;
-    pout.y[i] = qnan;
-    pout.z[i] = qnan;
+    pout.x[i] = boundary ? pin.x[i] : qnan;
+    pout.y[i] = boundary ? pin.y[i] : qnan;
+    pout.z[i] = boundary ? pin.z[i] : qnan;
     vout.x[i] = vin.x[i];
     vout.y[i] = vin.y[i];
     vout.z[i] = vin.z[i];
@@ -420,10 +428,10 @@ enum { kOpDiv = 0, kOpCurl = 1 };
 
 // Div (sph_field.go:203-227) / Curl (:272-294) of a tensor field t
 template <bool FAST, int OP>
-__global__ __launch_bounds__(kBlock) void k_field_div_curl(DevConsts c, Neigh nb, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_field_div_curl(DevConsts c, Neigh nb, Bnd bnd, CSoa3 p,
                                                            CSoa3 t, const float* __restrict__ rho, Soa3 out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  if (i >= live_n(c) || bnd.is(i)) return;
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   float div = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
   for_each_candidate(c, nb, xi, yi, zi, [&](int j) {
@@ -471,11 +479,11 @@ __device__ __forceinline__ float scalar_field(const DevConsts& c, int field, con
 
 // Laplacian (sph_field.go:230-248): sum_j m ((f_j - f_i)/rho_j) O2D(r)
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, Neigh nb, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_field_laplacian(DevConsts c, Neigh nb, Bnd bnd, CSoa3 p,
                                                             const float* __restrict__ rho, int field,
                                                             float* __restrict__ out) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  if (i >= live_n(c) || bnd.is(i)) return;
   const float xi = p.x[i], yi = p.y[i], zi = p.z[i];
   const float fi = scalar_field<FAST>(c, field, rho, i);
   float sum = 0.f;
@@ -517,11 +525,11 @@ __global__ __launch_bounds__(kBlock) void k_field_interpolate(DevConsts c, Neigh
 // ---------------------------------------------------------------------------------
 
 // predict :57-73 -- _vel += (F/m) dt ; _pos += _vel dt (state persists across steps)
-__global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, CSoa3 f, Soa3 pp, Soa3 pv,
+__global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, Bnd bnd, CSoa3 f, Soa3 pp, Soa3 pv,
                                                         const DevStats* stats) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  if (i >= live_n(c) || bnd.is(i)) return;  // the predictor loops over N() particles (pcisph_darwin.go:57-73)
   const float ax = f.x[i] * c.inv_mass, ay = f.y[i] * c.inv_mass, az = f.z[i] * c.inv_mass;
   const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
   const float tvx = pv.x[i] + dvx, tvy = pv.y[i] + dvy, tvz = pv.z[i] + dvz;
@@ -537,12 +545,12 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, CSoa3 f, So
 // DF + pressure accumulate :76-92 -- SPHField.DensityF (sph_field.go:137-152): starts at
 // W0, includes self, neighbours' CURRENT positions around the PREDICTED position.
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, Neigh nb, CSoa3 p,
+__global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, Neigh nb, Bnd bnd, CSoa3 p,
                                                         CSoa3 pp, float* __restrict__ press, DevStats* stats) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   unsigned int err_bits = 0u;
-  if (i < live_n(c)) {
+  if (i < live_n(c) && !bnd.is(i)) {  // (pcisph_darwin.go:76-92 loops over N() particles)
     const float xi = pp.x[i], yi = pp.y[i], zi = pp.z[i];
     float density = c.W0;
     for_each_candidate(c, nb, xi, yi, zi, [&](int j) {

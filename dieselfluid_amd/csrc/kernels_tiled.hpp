@@ -406,7 +406,7 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
 template <bool SHARE>
 __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
                                                           const int* __restrict__ n_tiles,
-                                                          const int* __restrict__ cell_start, CSoa3 p,
+                                                          const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
                                                           float* __restrict__ rho, float* __restrict__ pterm,
                                                           unsigned int* __restrict__ nmask, int mstride) {
   // Tiles are pipelined across the loop: while tile T is swept, the records of tile T+1 are on their
@@ -479,10 +479,13 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       int srow, off;
       tile_target(m, t, srow, off);
       const int g = m.row_gs[srow] + off;
-      float acc = 0.0f, acc1 = 0.0f;
+      float acc = 0.0f, acc1 = 0.0f, self_term = 1.0f;
       unsigned int mvalid = 0u;
       if (!ovf) {
         const float4 me = A[m.row_lds[srow] + off];
+        // a particle whose position has gone NaN (the reference produces such next to boundary particles)
+        // meets nobody, itself included: q is NaN, clamped to 0, for every candidate
+        self_term = (me.x == me.x && me.y == me.y && me.z == me.z) ? 1.0f : 0.0f;
         const float two_hh = 2.0f * c.inv_hh;
         const float sx = two_hh * me.x, sy = two_hh * me.y, sz = two_hh * me.z, a0 = 1.0f + me.w;
         const int lx = tile_target_cell(m, srow, off);
@@ -555,9 +558,14 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
         }
         if (sub != 0) return;
       }
-      if (!ovf) acc = (acc - 1.0f) * (c.mass * c.A);  // the particle met itself once (q = 1)
-      rho[g] = acc;
+      if (!ovf) acc = (acc - self_term) * (c.mass * c.A);  // the particle met itself once (q = 1)
       nmask[(size_t)kMaskValid * mstride + g] = mvalid;
+      if (bnd.is(g)) {  // a boundary particle reads as density 0, P/rho^2 = 0/0 (Bnd, sph_device.hpp)
+        rho[g] = 0.0f;
+        pterm[g] = __uint_as_float(0x7fc00000u);
+        return;
+      }
+      rho[g] = acc;
       // An isolated particle (rho = 0) has no neighbour for which the reference would ever form
       // P/rho^2 (sph_field.go:183-199 only does so inside the j != i loop); the masked sweeps do
       // visit the particle itself, so its own term has to be a harmless 0 rather than 0/0.
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
-    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats) {
+    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd) {
   if (share_stats != nullptr && share_wanted(share_stats) != SHARE) return;
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];  // x,y,z,P/rho^2
@@ -643,7 +651,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             o[0] = pin.x[g];
             o[1] = pin.y[g];
             o[2] = pin.z[g];
-            o[3] = WANT_G ? pterm[g] : 0.f;
+            o[3] = (WANT_G || bnd.ids != nullptr) ? pterm[g] : 0.f;  // (NaN marks a boundary particle)
             if constexpr (WANT_V || WANT_XS) {
               o[4] = vin.x[g];
               o[5] = vin.y[g];
@@ -653,11 +661,16 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           },
           [&](int slot, const float* o, bool real) {
             float4 a = make_float4(kFar, kFar, kFar, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (real) {
+            // (a particle whose position has gone NaN -- the reference produces such next to boundary
+            // particles -- is no one's neighbour there (dist < h is false); as a pad record it is none here
+            // either, also in the runs that are walked without a mask)
+            if (real && o[0] == o[0] && o[1] == o[1] && o[2] == o[2]) {
               a = make_float4(o[0], o[1], o[2], o[3]);
-              // 1/rho = 0 for an isolated particle (rho = 0): it only ever meets itself
+              // 1/rho = 0 for an isolated particle (rho = 0): it only ever meets itself.  A boundary
+              // particle (rho = 0 as well, P/rho^2 = NaN) is divided by as the reference does: 1/0 = +inf
               if constexpr (WANT_V || WANT_XS)
-                b = make_float4(o[4], o[5], o[6], o[7] > 0.0f ? __builtin_amdgcn_rcpf(o[7]) : 0.0f);
+                b = make_float4(o[4], o[5], o[6],
+                                o[7] > 0.0f ? __builtin_amdgcn_rcpf(o[7]) : (o[3] != o[3] ? __builtin_inff() : 0.0f));
             }
             A[slot] = a;
             if constexpr (WANT_V || WANT_XS) B[slot] = b;
@@ -697,6 +710,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           py = a.y;
           pz = a.z;
           pti_staged = a.w;
+          if (px == kFar) px = py = pz = __uint_as_float(0x7fc00000u);  // staged as a pad record: its position is NaN
           if constexpr (WANT_V || WANT_XS) {
             const float4 b = B[own];
             vx = b.x;
@@ -715,6 +729,19 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           vz = vin.z[g];
         }
         owned = !SLAB || OUT != kOutIntegrate || slab_owned(c, px, py, pz);
+        if (bnd.is(g)) {  // never a target: carried over unchanged (fused step) or left alone
+          if constexpr (OUT == kOutIntegrate) {
+            if (!SHARED || sub == 0) {
+              pout.x[g] = px;
+              pout.y[g] = py;
+              pout.z[g] = pz;
+              vout.x[g] = vin.x[g];
+              vout.y[g] = vin.y[g];
+              vout.z[g] = vin.z[g];
+            }
+          }
+          return;
+        }
         if constexpr (SLAB && OUT == kOutIntegrate) {
           // split slab step: this launch integrates the band cell layers or the others, not both
           if (owned && c.split_part != 0 && slab_band_cell(c, slab_axis_cell(c, px, py, pz)) != (c.split_part == 1)) return;
@@ -1049,7 +1076,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
                                                               const int* __restrict__ n_tiles,
-                                                              const int* __restrict__ cell_start, CSoa3 p, CSoa3 pp,
+                                                              const int* __restrict__ cell_start, Bnd bnd, CSoa3 p, CSoa3 pp,
                                                               float* __restrict__ press, DevStats* stats) {
   if (stats->pci_done) return;
   __shared__ TileMeta m;
@@ -1089,7 +1116,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       const int g = m.row_gs[srow] + off;
       // slab mode: a ghost's predicted density is meaningless (half a neighbourhood, no predictor
       // state) and must not decide the iteration's error
-      if (!slab_owned(c, p.x[g], p.y[g], p.z[g])) continue;
+      if (!slab_owned(c, p.x[g], p.y[g], p.z[g]) || bnd.is(g)) continue;
       const float qx = pp.x[g], qy = pp.y[g], qz = pp.z[g];
       // tile-local cell of the predicted position; the LDS image covers it and its 26
       // neighbours only while it stays inside the tile interior (1..4 per axis)

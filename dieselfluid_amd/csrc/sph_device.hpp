@@ -60,6 +60,19 @@ struct CSoa3 {
 
 __device__ __forceinline__ int live_n(const DevConsts& c) { return c.n_ptr ? *c.n_ptr : c.n; }
 
+// Boundary particles (particle_array.go:94-128, sph_field.go:75-85): position-only particles behind the
+// fluid in the reference's positions slice (index >= N()).  On the device they live in the same sorted
+// arrays -- a cell's slots are ascending in particle id, so fluid comes before boundary exactly as in
+// the reference's sample lists -- and are told apart by their id.  They are candidates of every
+// neighbour sum with Get()'s values (density 0, press 0, velocity 0: rho = 0, P/rho^2 = 0/0 = NaN,
+// v = 0 are what the arrays hold for them), never targets: no pass writes them, the integrators
+// carry them over unchanged.
+struct Bnd {
+  const int* ids;  // slot -> particle id; nullptr when the system has no boundary particles
+  int n_fluid;
+  __device__ __forceinline__ bool is(int slot) const { return ids != nullptr && ids[slot] >= n_fluid; }
+};
+
 // Host-visible counters living in device memory (fluid.go:25-26, pcisph_darwin.go:46-98).
 struct DevStats {
   unsigned int max_vel_bits;  // max |v|^2 (non-negative float bit patterns order like unsigned ints)

@@ -138,9 +138,20 @@ class SPHEngine:
         a = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
         self._ck(self._L.dsl_upload(self._h, b, _fp(a), a.size))
 
+    @property
+    def n_fluid(self) -> int:
+        """N(): particles that are not boundary particles (slab mode: the live count)"""
+        nb = int(self.params.n_boundary)
+        return self.n - nb if nb > 0 else self.n
+
+    def add_boundary_particles(self, positions):
+        """ParticleArray.AddBoundaryParticles (model/particle_array.go:123-128)"""
+        a = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1)
+        self._ck(self._L.dsl_add_boundary_particles(self._h, _fp(a), a.size))
+
     def download(self, name: str, sorted_order: bool = False) -> np.ndarray:
         b = BUF[name]
-        n = self.n
+        n = self.n if name == "positions" else self.n_fluid
         out = np.empty(n * _COMPS[b], dtype=np.float32)
         fn = self._L.dsl_download_sorted if sorted_order else self._L.dsl_download
         self._ck(fn(self._h, b, _fp(out), out.size))
@@ -297,17 +308,17 @@ class SPHEngine:
 
     # -- SPHField operators no solver calls (sph_field.go:124-135,203-294) ---------
     def field_div(self, tensor: str = "velocities") -> np.ndarray:
-        out = np.empty(self.n, dtype=np.float32)
+        out = np.empty(self.n_fluid, dtype=np.float32)
         self._ck(self._L.dsl_field_divergence(self._h, BUF[tensor], _fp(out), out.size))
         return out
 
     def field_curl(self, tensor: str = "velocities") -> np.ndarray:
-        out = np.empty(self.n * 3, dtype=np.float32)
+        out = np.empty(self.n_fluid * 3, dtype=np.float32)
         self._ck(self._L.dsl_field_curl(self._h, BUF[tensor], _fp(out), out.size))
         return out.reshape(-1, 3)
 
     def field_laplacian(self, scalar: str = "densities") -> np.ndarray:
-        out = np.empty(self.n, dtype=np.float32)
+        out = np.empty(self.n_fluid, dtype=np.float32)
         self._ck(self._L.dsl_field_laplacian(self._h, BUF[scalar], _fp(out), out.size))
         return out
 

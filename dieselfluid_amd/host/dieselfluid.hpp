@@ -18,6 +18,7 @@
 //   dsl::Chan<T>                  Go unbuffered channel used by the drivers
 #pragma once
 
+#include <array>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -121,17 +122,45 @@ inline std::vector<float> LatticePositions(int n3, const float* origin, int orig
   return pos;
 }
 
+}  // namespace sph
+
+// geom/mesh/mesh.go: the part of Mesh the SPH path touches
+namespace mesh {
+struct Mesh {
+  std::vector<std::array<float, 3>> Vertexes;
+  // mesh.go:60-76: one particle per vertex (`density` is unused there too); the bound check
+  // `x < len(particle_list)-3` leaves the LAST vertex's particle at the origin
+  std::vector<float> GenerateBoundaryParticles(float /*density*/) const {
+    const int len = (int)Vertexes.size() * 3;
+    std::vector<float> particle_list((size_t)len, 0.0f);
+    for (int index = 0; index < (int)Vertexes.size(); ++index) {
+      const int x = index * 3;
+      if (x < len - 3) {
+        particle_list[(size_t)x] = Vertexes[(size_t)index][0];
+        particle_list[(size_t)x + 1] = Vertexes[(size_t)index][1];
+        particle_list[(size_t)x + 2] = Vertexes[(size_t)index][2];
+      }
+    }
+    return particle_list;
+  }
+};
+}  // namespace mesh
+
+namespace sph {
+
 class SPH {
  public:
   // sph.Init(scl, origin, colliders, n3, pci)  fluid.go:41-88.  `colliders` is accepted and
-  // ignored exactly as the reference does (BoundaryParticles is commented out, fluid.go:70).
-  static SPH Init(float scl, const std::vector<float>& origin, const void* colliders, int n3, bool pci, int device = 0,
-                  int math_mode = DSL_MATH_EXACT) {
+  // ignored exactly as the reference does (BoundaryParticles is commented out, fluid.go:70);
+  // `boundary_capacity` reserves device slots for a later BoundaryParticles() call.
+  static SPH Init(float scl, const std::vector<float>& origin, const std::vector<mesh::Mesh*>* colliders, int n3, bool pci,
+                  int device = 0, int math_mode = DSL_MATH_EXACT, int boundary_capacity = 0) {
     (void)scl;
     (void)colliders;
     SPH core;
     if (dsl_params_reference(&core.prm_, n3) != DSL_OK) throw Error(dsl_last_error(nullptr));
     core.prm_.math_mode = math_mode;
+    if (boundary_capacity > 0) core.prm_.capacity = core.prm_.n_particles + boundary_capacity;
     core.particles_ = core.prm_.n_particles;
     core.cache_life_ = CACHE_L;
     core.mu_ = VISCOSITY_WATER;
@@ -167,10 +196,24 @@ class SPH {
       mu_ = o.mu_;
       delta_ = o.delta_;
       particles_ = o.particles_;
+      boundary_ = o.boundary_;
     }
     return *this;
   }
   ~SPH() { release(); }
+
+  // SPHField.BoundaryParticles (model/field/sph_field.go:75-85): every collider's vertex particles go
+  // to ParticleArray.AddBoundaryParticles (particle_array.go:123-128); returns the last collider's list
+  std::vector<float> BoundaryParticles(const std::vector<mesh::Mesh*>& colliders) {
+    std::vector<float> colliderPositions;
+    for (mesh::Mesh* m : colliders) {
+      colliderPositions = m->GenerateBoundaryParticles(2.0f);
+      if (!colliderPositions.empty()) ck(dsl_add_boundary_particles(h_, colliderPositions.data(), colliderPositions.size()));
+      boundary_ += (int)colliderPositions.size() / 3;
+    }
+    return colliderPositions;
+  }
+  int Total() const { return particles_ + boundary_; }  // particle_array.go:134-136
 
   int N() const { return particles_; }                 // fluid.go:106-108
   void NN() { ck(dsl_build_neighbours(h_)); }          // fluid.go:100-102
@@ -211,7 +254,11 @@ class SPH {
 
   // ParticleArray accessors (model/particle_array.go:39-54): blocking device reads in the
   // reference's host layout (xyz interleaved).
-  std::vector<float> Positions() { return read(DSL_BUF_POSITIONS, 3); }
+  std::vector<float> Positions() {  // Total() particles (particle_array.go:21)
+    std::vector<float> out((size_t)Total() * 3);
+    ck(dsl_download(h_, DSL_BUF_POSITIONS, out.data(), out.size()));
+    return out;
+  }
   std::vector<float> Velocities() { return read(DSL_BUF_VELOCITIES, 3); }
   std::vector<float> Forces() { return read(DSL_BUF_FORCES, 3); }
   std::vector<float> Densities() { return read(DSL_BUF_DENSITIES, 1); }
@@ -301,7 +348,7 @@ class SPH {
   dsl_params prm_{};
   dsl_handle* h_ = nullptr;
   float time_ = 0.0f, cache_life_ = CACHE_L, mu_ = VISCOSITY_WATER, delta_ = 0.0f;
-  int particles_ = 0;
+  int particles_ = 0, boundary_ = 0;
 };
 
 }  // namespace sph
@@ -433,6 +480,89 @@ class ComputeGPU {
   std::string Queue(const std::string& name) {                    // gpu.go:286-296
     if (!kernels_.count(name)) return "kernel [" + name + "] not registered";
     pending_ = name;
+    return "";
+  }
+  // ---- the rest of compute.GPUCompute (compute/compute.go:26-53) ----
+  bool Setup(bool /*gl_interop*/) { return HasDeviceContext(); }   // compute.go:29: the device context is the handle
+  // compute.go:33 Run(x chan int): runs the kernel named by the last Queue() -- the reference's two fused
+  // device kernels are phases of the PCISPH step here (pci_density.c:12-23 = NN, density, viscosity;
+  // pci_predict.c:9-27 = the correction loop + integrate) -- then reports THREAD_DONE / THREAD_ERR
+  void Run(Chan<int>& x) {
+    int rc = DSL_OK;
+    dsl_handle* h = sys_->handle();
+    if (pending_ == "compute_density") {
+      rc = dsl_pcisph_begin(h);  // (re-copies the predictor state only the first time it is needed)
+      if (rc == DSL_OK) rc = dsl_pcisph_phase(h, DSL_PCI_BEGIN_STEP);
+    } else if (pending_ == "predict_correct") {
+      for (int it = 0; rc == DSL_OK && it < sys_->params().pci_max_iters; ++it) {
+        rc = dsl_pcisph_phase(h, DSL_PCI_ITERATE);
+        if (rc == DSL_OK) rc = dsl_pcisph_phase(h, DSL_PCI_CHECK);
+      }
+      if (rc == DSL_OK) rc = dsl_pcisph_phase(h, DSL_PCI_END_STEP);
+    } else {
+      rc = DSL_ERR_INVALID;
+    }
+    if (rc == DSL_OK) rc = dsl_sync(h);
+    x.send(rc == DSL_OK ? THREAD_DONE : THREAD_ERR);
+  }
+  // gpu.go:354-378.  "sizes" = {N, Nboundary, buckets, bucket_size} (pcisph_gpu_darwin.go:60): checked
+  // against the engine's parameters instead of being dropped; "sampler" = the host's flattened LSH
+  // table (lsh.go:70-80): the engine builds its own neighbour table, the upload is accepted and ignored.
+  std::string PassIntBuffer(const std::vector<int>& cpu, const std::string& name) {
+    if (!aux_.count(name) && !registered_.count(name)) return "buffer [" + name + "] not registered";
+    if (name == "sizes") {
+      const dsl_params& p = sys_->params();
+      if (cpu.size() < 2 || cpu[0] != p.n_particles || cpu[1] != p.n_boundary)
+        return "sizes block {N, Nboundary, ..} does not match the engine's parameters";
+    }
+    log_ += "Passed Integer Buffer " + name + "\n";
+    return "";
+  }
+  std::string ReadIntBuffer(std::vector<int>& cpu, const std::string& name) {
+    if (!aux_.count(name) && !registered_.count(name)) return "buffer [" + name + "] not registered";
+    const dsl_params& p = sys_->params();
+    if (name == "sizes") {
+      const int v[4] = {p.n_particles, p.n_boundary, p.lsh_buckets, p.lsh_bucket_size};
+      for (size_t k = 0; k < cpu.size() && k < 4; ++k) cpu[k] = v[k];
+      return "";
+    }
+    if (name == "sampler") {  // HashSampler.GetData1D (DSL_NEIGH_LSH_REF handles only)
+      std::vector<int32_t> t(cpu.size());
+      if (dsl_lsh_download_table(sys_->handle(), t.data(), t.size()) != DSL_OK) return dsl_last_error(sys_->handle());
+      for (size_t k = 0; k < cpu.size(); ++k) cpu[k] = t[k];
+      return "";
+    }
+    return "buffer [" + name + "] holds no integers";
+  }
+  // gpu.go:378-390 PassLayoutBuffer for the two parameter blocks of pcisph_gpu_darwin.go:60-61
+  std::string PassLayoutBuffer(const void* data, int bytes, const std::string& name) {
+    if (!aux_.count(name)) return "buffer [" + name + "] not registered";
+    const dsl_params& p = sys_->params();
+    if (name == "floats" && bytes >= 20) {  // {dt, mass, delta, maxVel, h}
+      const float* f = static_cast<const float*>(data);
+      if (f[0] != p.dt || f[1] != p.mass || f[4] != p.h) return "floats block {dt, mass, delta, maxVel, h} does not match the engine's parameters";
+    }
+    if (name == "sizes" && bytes >= 8) {
+      const int32_t* v = static_cast<const int32_t*>(data);
+      if (v[0] != p.n_particles || v[1] != p.n_boundary) return "sizes block {N, Nboundary, ..} does not match the engine's parameters";
+    }
+    log_ += "Passed Layout Buffer " + name + "\n";
+    return "";
+  }
+  std::string AddSourceString(const std::string&) { return ""; }  // compute.go:46: nothing to compile
+  // gpu.go:323-330 RegisterGLBuffer shares a GL buffer with the device queue so that the renderer draws what
+  // the solver wrote without a read-back.  The counterpart here is the other way round: the consumer is
+  // handed the live device arrays (dsl_device_pointers); the GL id is recorded, nothing is mapped.
+  std::string RegisterGLBuffer(uint32_t gl_buffer_id, int size, const std::string& name) {
+    if (buffer_id(name) != DSL_BUF_POSITIONS) return "only the positions buffer has a render hand-off";
+    registered_[name] = size;
+    log_ += "RegisterGLBuffer() - buffer " + name + " (GL id " + std::to_string(gl_buffer_id) +
+            "): read the device arrays through DevicePointers()\n";
+    return "";
+  }
+  // the live SoA device arrays of the positions (x, y, z), slot -> particle id map, slot count
+  std::string DevicePointers(const float* xyz[3], const int32_t** ids, int* n) {
+    if (dsl_device_pointers(sys_->handle(), DSL_BUF_POSITIONS, xyz, ids, n) != DSL_OK) return dsl_last_error(sys_->handle());
     return "";
   }
   void Set(const Descriptor& d) { *desc_ = d; }     // gpu.go:298-300

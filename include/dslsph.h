@@ -69,7 +69,7 @@ typedef struct dsl_params {
   uint32_t abi_version; /* = DSL_ABI_VERSION               */
   /* "sizes" */
   int32_t n_particles;     /* field.Particles.N()                   */
-  int32_t n_boundary;      /* Total()-N(); must be 0 (fluid.go:70)  */
+  int32_t n_boundary;      /* Total()-N() (0 in sph.Init: fluid.go:70) */
   int32_t lsh_buckets;     /* carried for the Go side; unused here  */
   int32_t lsh_bucket_size; /* carried for the Go side; unused here  */
   /* "floats" */
@@ -165,6 +165,23 @@ int dsl_get_params(dsl_handle *h, dsl_params *out);
  * `count` is the number of floats and must match the buffer. */
 int dsl_upload(dsl_handle *h, int buffer, const float *host, size_t count);
 int dsl_download(dsl_handle *h, int buffer, float *host, size_t count);
+
+/* ParticleArray.AddBoundaryParticles (model/particle_array.go:123-128; fed by SPHField.BoundaryParticles,
+ * model/field/sph_field.go:75-85, from Mesh.GenerateBoundaryParticles, geom/mesh/mesh.go:60-76):
+ * appends count/3 position-only particles behind the current ones; needs room in
+ * dsl_params.capacity.  dsl_params.n_boundary > 0 at creation is the same as NewParticleArray(n, nb, ..):
+ * nb zero-filled boundary slots.  With boundary particles DSL_BUF_POSITIONS holds Total() = N + Nb
+ * particles (fluid first), every other buffer N.
+ * Semantics are the reference's, quirks included (oracle/dsl_oracle.c restates them first):
+ *   - boundary particles are candidates of every neighbour sum with Get()'s values: position, density
+ *     0, press 0, velocity 0 (particle_array.go:94-117); Density/DensityF simply count them
+ *     (sph_field.go:143,163), Gradient and LaplacianForce divide by their density 0 without a guard
+ *     (sph_field.go:183,259): a fluid particle with a boundary neighbour gets NaN / Inf there;
+ *   - Get(N()) -- the FIRST boundary particle -- is the zero particle: it takes part in every sum at the
+ *     origin, while the positions slice keeps (and dsl_download returns) what was uploaded;
+ *   - no pass writes a boundary particle; Update does not move it.
+ * Not available in slab mode or after dsl_set_ids. */
+int dsl_add_boundary_particles(dsl_handle *h, const float *host_positions, size_t count);
 
 /* Render hand-off without the per-step full read-back of pcisph_gpu_darwin.go:276-277
  * (SURVEY 8f rank 1):

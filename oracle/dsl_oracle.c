@@ -323,11 +323,20 @@ static void grid_update(dslo_sph *s) {
   dslo_sampler *g = &s->smp;
   int total = parts_total(&s->parts);
   memset(g->cell_start, 0, sizeof(int) * ((size_t)g->ncell + 1));
-  for (int i = 0; i < total; i++) g->cell_start[grid_cell_of(g, &s->parts.positions[3 * i]) + 1]++;
+  /* binned where Get(i) says the particle is, as HashSampler.UpdateSampler hashes Get(i).Position
+   * (lsh.go:126-133): index == n_particles, the first boundary particle, reads as the origin
+   * (particle_array.go:94-117) */
+  for (int i = 0; i < total; i++) {
+    dslo_particle q = dslo_particles_get(&s->parts, i);
+    g->cell_start[grid_cell_of(g, q.position) + 1]++;
+  }
   for (int c = 0; c < g->ncell; c++) g->cell_start[c + 1] += g->cell_start[c];
   int *fill = (int *)malloc(sizeof(int) * ((size_t)g->ncell + 1));
   memcpy(fill, g->cell_start, sizeof(int) * ((size_t)g->ncell + 1));
-  for (int i = 0; i < total; i++) g->cell_items[fill[grid_cell_of(g, &s->parts.positions[3 * i])]++] = i;
+  for (int i = 0; i < total; i++) {
+    dslo_particle q = dslo_particles_get(&s->parts, i);
+    g->cell_items[fill[grid_cell_of(g, q.position)]++] = i;
+  }
   free(fill);
 }
 
@@ -556,6 +565,43 @@ dslo_sph *dslo_sph_from_state(const dslo_params *prm, int n, const float *pos, c
   s->time = prm->dt;
   dslo_sampler_update(s);
   return s;
+}
+
+/* particle_array.go:123-128 AddBoundaryParticles: appends position-only particles behind the fluid
+ * (n_boundary grows; velocities, densities, forces, pressures keep n_particles entries), then the
+ * sampler is rebuilt over Total() particles (lsh.go:126-133).  Returns the new Total(). */
+int dslo_sph_add_boundary(dslo_sph *s, const float *positions, int nb) {
+  dslo_particles *p = &s->parts;
+  int total = parts_total(p);
+  float *np = (float *)realloc(p->positions, sizeof(float) * ((size_t)(total + nb) * 3 + 1));
+  if (!np) return -1;
+  p->positions = np;
+  memcpy(p->positions + (size_t)total * 3, positions, sizeof(float) * (size_t)nb * 3);
+  p->n_boundary += nb;
+  if (s->smp.cell_items) {
+    int *ci = (int *)realloc(s->smp.cell_items, sizeof(int) * ((size_t)parts_total(p) + 1));
+    if (!ci) return -1;
+    s->smp.cell_items = ci;
+  }
+  dslo_sampler_update(s);
+  return parts_total(p);
+}
+
+/* geom/mesh/mesh.go:60-76 Mesh.GenerateBoundaryParticles(density): one particle per vertex (the
+ * density argument is unused); `if x < len(particle_list)-3` leaves the LAST vertex's particle at the
+ * origin.  out: nverts*3 floats.  model/field/sph_field.go:75-85 BoundaryParticles feeds every
+ * collider's list to AddBoundaryParticles. */
+void dslo_mesh_boundary_particles(const float *vertices, int nverts, float *out) {
+  int len = nverts * 3;
+  for (int i = 0; i < len; i++) out[i] = 0.0f;
+  for (int index = 0; index < nverts; index++) {
+    int x = index * 3;
+    if (x < len - 3) {
+      out[x] = vertices[x];
+      out[x + 1] = vertices[x + 1];
+      out[x + 2] = vertices[x + 2];
+    }
+  }
 }
 
 void dslo_sph_free(dslo_sph *s) {
@@ -1132,6 +1178,7 @@ void dslo_dambreak_positions(int n3, float dx, float jitter, uint64_t seed, floa
  * accessors for the ctypes test harness (oracle/pyoracle.py)
  * ===================================================================================== */
 int dslo_n(const dslo_sph *s) { return s->parts.n_particles; }
+int dslo_total(const dslo_sph *s) { return s->parts.n_particles + s->parts.n_boundary; }
 float *dslo_positions(dslo_sph *s) { return s->parts.positions; }
 float *dslo_velocities(dslo_sph *s) { return s->parts.velocities; }
 float *dslo_forces(dslo_sph *s) { return s->parts.forces; }

@@ -187,6 +187,9 @@ dslo_sph *dslo_sph_from_state(const dslo_params *prm, int n, const float *pos,
                               const float *vel, const float *force,
                               const float *hash_vectors, int hash_bits);
 void dslo_sph_free(dslo_sph *s);
+/* boundary particles: particle_array.go:123-128, sph_field.go:75-85, geom/mesh/mesh.go:60-76 */
+int dslo_sph_add_boundary(dslo_sph *s, const float *positions, int nb);
+void dslo_mesh_boundary_particles(const float *vertices, int nverts, float *out);
 
 /* ---- passes: model/sph/fluid.go:111-277 ---------------------------------------- */
 float dslo_cfl(dslo_sph *s);

@@ -118,6 +118,9 @@ def lib() -> C.CDLL:
         "dslo_sph_init": (vp, [C.POINTER(Params), fp, C.c_int, fp, C.c_int, C.c_int]),
         "dslo_sph_from_state": (vp, [C.POINTER(Params), C.c_int, fp, fp, fp, fp, C.c_int]),
         "dslo_sph_free": (None, [vp]),
+        "dslo_sph_add_boundary": (C.c_int, [vp, fp, C.c_int]),
+        "dslo_mesh_boundary_particles": (None, [fp, C.c_int, fp]),
+        "dslo_total": (C.c_int, [vp]),
         "dslo_cfl": (C.c_float, [vp]),
         "dslo_density_all": (None, [vp]),
         "dslo_pressure_all": (None, [vp]),
@@ -191,6 +194,15 @@ def params_reference(n3: int) -> Params:
 def set_vec(field, v):
     for i in range(3):
         field[i] = float(v[i])
+
+
+def mesh_boundary_particles(vertices) -> np.ndarray:
+    """Mesh.GenerateBoundaryParticles (geom/mesh/mesh.go:60-76): one particle per vertex, the last one left at
+    the origin by the reference's bound check"""
+    v = f32(vertices).reshape(-1, 3)
+    out = np.zeros_like(v)
+    lib().dslo_mesh_boundary_particles(_fp(v), v.shape[0], _fp(out))
+    return out
 
 
 def default_hash_vectors(seed: int = 7) -> np.ndarray:
@@ -275,6 +287,21 @@ class OracleSPH:
 
     def positions(self):
         return self._view(self._L.dslo_positions, 3).copy()
+
+    # -- boundary particles (particle_array.go:123-128, mesh.go:60-76) -------------------------
+    def add_boundary(self, positions):
+        """ParticleArray.AddBoundaryParticles + a sampler rebuild; returns Total()"""
+        a = f32(positions).reshape(-1, 3)
+        return int(self._L.dslo_sph_add_boundary(self._h, _fp(a), a.shape[0]))
+
+    @property
+    def total(self) -> int:
+        return int(self._L.dslo_total(self._h))
+
+    def all_positions(self):
+        """positions of the Total() = N + Nb particles (the reference's positions slice)"""
+        ptr = self._L.dslo_positions(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(self.total * 3,)).reshape(-1, 3).copy()
 
     def velocities(self):
         return self._view(self._L.dslo_velocities, 3).copy()
