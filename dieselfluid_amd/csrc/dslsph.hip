@@ -46,7 +46,7 @@ struct dsl_handle {
   // boundary particles (particle_array.go:123-128): ids n_fluid .. n-1.  The reference's Get() reads
   // index == N() as the zero particle (particle_array.go:98,107), so the first boundary particle takes
   // part in every sum AT THE ORIGIN; the device copy holds (0,0,0) for it and b0_pos what was uploaded.
-  int n_fluid = 0;
+  int nb = 0;  // boundary particles; N() = n - nb (n itself changes in slab mode, where nb is always 0)
   float b0_pos[3] = {0.f, 0.f, 0.f};
   bool ids_global = false;  // dsl_set_ids replaced the host-order map
   int* dcounter = nullptr;
@@ -263,7 +263,8 @@ CSoa3 cfrc(dsl_handle* h) { return {h->frc[h->cur_f][0], h->frc[h->cur_f][1], h-
 Soa3 mpcip(dsl_handle* h) { return {h->pci[h->cur_pci][0], h->pci[h->cur_pci][1], h->pci[h->cur_pci][2]}; }
 Soa3 mpciv(dsl_handle* h) { return {h->pci[h->cur_pci][3], h->pci[h->cur_pci][4], h->pci[h->cur_pci][5]}; }
 
-Bnd bnd_of(const dsl_handle* h) { return Bnd{h->n > h->n_fluid ? h->ids[h->cur_ids] : nullptr, h->n_fluid}; }
+inline int n_fluid_of(const dsl_handle* h) { return h->n - h->nb; }
+Bnd bnd_of(const dsl_handle* h) { return Bnd{h->nb > 0 ? h->ids[h->cur_ids] : nullptr, n_fluid_of(h)}; }
 
 Neigh neigh(const dsl_handle* h) {
   if (h->lsh) return Neigh{h->cell_start, h->lsh_samples, h->hashv, h->lsh_bits, h->prm.lsh_buckets};
@@ -752,7 +753,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     return rc;
   }
   h->n = h->c.n;
-  h->n_fluid = params->n_particles;
+  h->nb = params->n_boundary;
   h->cap = params->capacity > 0 ? params->capacity : h->n;
   h->ncell = h->c.ncell;
   h->ncell_pad = ((h->ncell + 1 + kScanTile - 1) / kScanTile) * kScanTile;
@@ -907,8 +908,8 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
   // positions hold Total() particles, everything else N() (particle_array.go:18-33)
-  const bool with_boundary = h->n > h->n_fluid;
-  const int limit = (buffer == DSL_BUF_POSITIONS || !with_boundary) ? ncur : h->n_fluid;
+  const bool with_boundary = h->nb > 0;
+  const int limit = (buffer == DSL_BUF_POSITIONS || !with_boundary) ? ncur : n_fluid_of(h);
   const size_t n = (size_t)ncur;
   if (count != (size_t)limit * bi.comps)
     return fail(h, DSL_ERR_INVALID,
@@ -921,8 +922,8 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
   switch (buffer) {
     case DSL_BUF_POSITIONS: {
       Soa3 p = mpos(h, h->cur_pv);
-      const int zero_id = with_boundary ? h->n_fluid : -1;  // Get(N()) is the zero particle (particle_array.go:98,107)
-      if (with_boundary) std::memcpy(h->b0_pos, host + (size_t)3 * h->n_fluid, sizeof(h->b0_pos));
+      const int zero_id = with_boundary ? n_fluid_of(h) : -1;  // Get(N()) is the zero particle (particle_array.go:98,107)
+      if (with_boundary) std::memcpy(h->b0_pos, host + (size_t)3 * n_fluid_of(h), sizeof(h->b0_pos));
       hipLaunchKernelGGL(k_unpack3, g, b, 0, h->stream, h->n, h->stage, ids, p.x, p.y, p.z, limit, zero_id);
       h->grid_valid = false;
       h->masks_valid = false;
@@ -981,7 +982,8 @@ int dsl_add_boundary_particles(dsl_handle* h, const float* host_positions, size_
   if ((long long)h->n + nb > h->cap)
     return fail(h, DSL_ERR_NOMEM, "dsl_add_boundary_particles: dsl_params.capacity leaves no room (needs n_particles + all boundary particles)");
   HIP_TRY(h, hipMemcpyAsync(h->stage, host_positions, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  const bool first = h->n == h->n_fluid;
+  const bool first = h->nb == 0;
+  const int n_fluid = n_fluid_of(h);
   if (first) std::memcpy(h->b0_pos, host_positions, sizeof(h->b0_pos));
   Soa3 p = mpos(h, h->cur_pv), v = mvel(h, h->cur_pv);
   Soa3 pcip{nullptr, nullptr, nullptr}, pciv{nullptr, nullptr, nullptr};
@@ -989,11 +991,12 @@ int dsl_add_boundary_particles(dsl_handle* h, const float* host_positions, size_
     pcip = mpcip(h);
     pciv = mpciv(h);
   }
-  hipLaunchKernelGGL(k_append_boundary, dim3(grid_for(nb)), dim3(kBlock), 0, h->stream, nb, h->n, h->n, h->n_fluid, h->stage,
+  hipLaunchKernelGGL(k_append_boundary, dim3(grid_for(nb)), dim3(kBlock), 0, h->stream, nb, h->n, h->n, n_fluid, h->stage,
                      p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], pcip, pciv);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->n += nb;
+  h->nb += nb;
   h->c.n = h->n;
   h->prm.n_boundary += nb;
   h->grid_valid = false;
@@ -1008,8 +1011,8 @@ static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, i
   if (!host || !buf_info(buffer, bi)) return fail(h, DSL_ERR_INVALID, "dsl_download: bad buffer id or null pointer");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
-  const bool with_boundary = h->n > h->n_fluid;
-  const int limit = (buffer == DSL_BUF_POSITIONS || !with_boundary) ? ncur : h->n_fluid;
+  const bool with_boundary = h->nb > 0;
+  const int limit = (buffer == DSL_BUF_POSITIONS || !with_boundary) ? ncur : n_fluid_of(h);
   if (with_boundary && sorted_order && buffer != DSL_BUF_POSITIONS)
     return fail(h, DSL_ERR_UNSUPPORTED, "dsl_download_sorted: with boundary particles only positions have a slot-order image");
   if (count != (size_t)limit * bi.comps)
@@ -1056,7 +1059,7 @@ static int download_impl(dsl_handle* h, int buffer, float* host, size_t count, i
   HIP_TRY(h, hipMemcpyAsync(host, h->stage, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   // the positions slice itself keeps what was uploaded for particle N(); only Get() reads it as the origin
-  if (with_boundary && buffer == DSL_BUF_POSITIONS && !sorted_order) std::memcpy(host + (size_t)3 * h->n_fluid, h->b0_pos, sizeof(h->b0_pos));
+  if (with_boundary && buffer == DSL_BUF_POSITIONS && !sorted_order) std::memcpy(host + (size_t)3 * n_fluid_of(h), h->b0_pos, sizeof(h->b0_pos));
   return DSL_OK;
 }
 
@@ -1215,7 +1218,7 @@ static int field_div_curl(dsl_handle* h, int tensor_buffer, float* host_out, siz
   CHECK_HANDLE(h);
   int n = 0;
   if (int rc = field_prepare(h, &n)) return rc;
-  if (!host_out || count != (size_t)h->n_fluid * (curl ? 3 : 1)) return fail(h, DSL_ERR_INVALID, "field operator: bad output size");
+  if (!host_out || count != (size_t)n_fluid_of(h) * (curl ? 3 : 1)) return fail(h, DSL_ERR_INVALID, "field operator: bad output size");
   CSoa3 t;
   if (tensor_buffer == DSL_BUF_VELOCITIES) t = cvel(h);
   else if (tensor_buffer == DSL_BUF_FORCES) {
@@ -1260,7 +1263,7 @@ int dsl_field_laplacian(dsl_handle* h, int scalar_buffer, float* host_out, size_
   int n = 0;
   if (int rc = field_prepare(h, &n)) return rc;
   const int field = scalar_field_id(scalar_buffer);
-  if (!host_out || count != (size_t)h->n_fluid || field < 0) return fail(h, DSL_ERR_INVALID, "dsl_field_laplacian: bad argument");
+  if (!host_out || count != (size_t)n_fluid_of(h) || field < 0) return fail(h, DSL_ERR_INVALID, "dsl_field_laplacian: bad argument");
   CSoa3 p = cpos(h);
   by_math(h, [&](auto fast) {
     hipLaunchKernelGGL((k_field_laplacian<decltype(fast)::value>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, h->c,
@@ -1458,7 +1461,7 @@ int dsl_slab_config(dsl_handle* h, int axis, float lo, float hi) {
   CHECK_HANDLE(h);
   if (axis < -1 || axis > 2 || !(lo < hi)) return fail(h, DSL_ERR_INVALID, "dsl_slab_config: bad axis or empty range");
   if (h->lsh) return fail(h, DSL_ERR_UNSUPPORTED, "lsh_ref buckets are angular cones through the whole domain: no slabs");
-  if (axis >= 0 && h->n > h->n_fluid) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_slab_config: boundary particles are not supported in slab mode");
+  if (axis >= 0 && h->nb > 0) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_slab_config: boundary particles are not supported in slab mode");
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
   h->c.slab_axis = axis;
@@ -2036,7 +2039,7 @@ int dsl_set_ids(dsl_handle* h, const int32_t* ids, size_t count) {
   int ncur = 0;
   if (int rc = host_count(h, &ncur)) return rc;
   if (!ids || count != (size_t)ncur) return fail(h, DSL_ERR_INVALID, "dsl_set_ids: count must equal the particle count");
-  if (h->n > h->n_fluid) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_set_ids: boundary particles are told apart by their ids");
+  if (h->nb > 0) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_set_ids: boundary particles are told apart by their ids");
   // ids follow the host order of dsl_upload: slot s currently holds host index cur_ids[s]
   std::vector<int> cur(count), out(count);
   HIP_TRY(h, hipMemcpyAsync(cur.data(), h->ids[h->cur_ids], count * sizeof(int), hipMemcpyDeviceToHost, h->stream));

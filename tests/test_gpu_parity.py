@@ -356,10 +356,16 @@ def test_render_handoff_decimated_and_device_pointers():
 def test_error_paths_do_not_abort():
     from dieselfluid_amd import SPHEngine, DslError, scenes
     p, pos = scenes.reference_scene(4)
-    p.n_boundary = 3
+    p.n_boundary = -3
     with pytest.raises(DslError):
         SPHEngine(p)
     p.n_boundary = 0
+    p.capacity = p.n_particles - 1
+    with pytest.raises(DslError):
+        SPHEngine(p)
+    p.capacity = 0
     eng = SPHEngine(p)
+    with pytest.raises(DslError):
+        eng.add_boundary_particles(pos[:2])  # no room: capacity == n_particles
     with pytest.raises(DslError):
         eng.upload("positions", pos[:-1])
