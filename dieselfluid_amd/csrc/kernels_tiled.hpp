@@ -597,7 +597,7 @@ constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
 template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false, bool SHARE = true>
 // (Two 8-wave workgroups per CU need <= 128 VGPRs.  The headline instantiation gets there on its
 // own and schedules best unconstrained; the others are held to 4 waves/SIMD.)
-__global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
+__global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && !SHARE && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
     const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
@@ -827,7 +827,11 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
               je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
             };
-            auto walk_run = [&](int ri, int j, const int je, unsigned int first_word) {
+            // `second_word`: the mask of candidates 32-63, requested by the caller together with the first
+            // word.  (Once the lattice has melted ~10 % of the runs are that long, so in nearly every run
+            // of a wave SOME lane needs its second word: fetched here, inside the walk, that was one exposed
+            // HBM latency per run and wave.)
+            auto walk_run = [&](int ri, int j, const int je, unsigned int first_word, unsigned int second_word) {
               const bool has_mask = (runs_masked >> ri) & 1u;
               int word = ri;
               do {
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
                 int top = j + clen - 1;
                 if (has_mask) {  // (then the run has at most 64 candidates: two words)
-                  mm = word == ri ? first_word : nmask[(size_t)word * mstride + g];
+                  mm = word == ri ? first_word : second_word;
                   top = j + ((clen + 3) & ~3) - 1;
                   word = kMaskHigh + ri;
                 }
@@ -890,23 +894,30 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                   first_pass ? pre_word : (nmask != nullptr ? nmask[(size_t)rn * mstride + g] : 0u);  // (not behind runs_masked)
               int jn, jen;
               run_bounds(rn, jn, jen);
+              auto second_of = [&](int ri, int j, int je) {
+                return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? nmask[(size_t)(kMaskHigh + ri) * mstride + g] : 0u;
+              };
+              unsigned int ahead2 = second_of(rn, jn, jen);
 #pragma unroll 1
               for (int s = 0; s < 9; ++s) {
-                const unsigned int word = ahead;
+                const unsigned int word = ahead, word2 = ahead2;
                 const int j = jn, je = jen, ri = rn;
                 if (s < 8) {
                   rn = run_of(s + 1);
                   if (runs_masked != 0u) ahead = nmask[(size_t)rn * mstride + g];
                   run_bounds(rn, jn, jen);
+                  ahead2 = second_of(rn, jn, jen);
                 }
-                walk_run(ri, j, je, word);
+                walk_run(ri, j, je, word, word2);
               }
             } else {
 #pragma unroll 1
               for (int ri = sub; ri < 9; ri += k) {
                 int j, je;
                 run_bounds(ri, j, je);
-                walk_run(ri, j, je, ((runs_masked >> ri) & 1u) ? nmask[(size_t)ri * mstride + g] : 0u);
+                const bool masked = (runs_masked >> ri) & 1u;
+                walk_run(ri, j, je, masked ? nmask[(size_t)ri * mstride + g] : 0u,
+                         (masked && je - j > 32) ? nmask[(size_t)(kMaskHigh + ri) * mstride + g] : 0u);
               }
             }
             DSL_STAMP(t5);
