@@ -143,6 +143,12 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   c.hh = hh * hh;
   c.inv_h = 1.0f / hh;
   c.inv_hh = 1.0f / c.hh;
+  {  // std::sqrt(float) is correctly rounded and monotone: walk to the first float whose root reaches h
+    float t = c.hh;
+    while (std::sqrt(t) >= hh && t > 0.0f) t = std::nextafter(t, 0.0f);
+    while (std::sqrt(t) < hh) t = std::nextafter(t, INFINITY);
+    c.r2_thr = t;
+  }
   const float H3 = hh * hh * hh, H4 = hh * hh * hh * hh, H5 = hh * hh * hh * hh * hh;
   const double PI = 3.141592653589;  // kernel/std_kernel.go:5
   c.A = 315.0f / ((float)(64.0 * PI) * H3);
@@ -327,7 +333,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   rc = timed(h, DSL_K_SCAN, [&] {
     hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan, h->dstats,
-                       h->prm.math_mode == DSL_MATH_FAST ? h->n_tiles : nullptr);
+                       !h->lsh ? h->n_tiles : nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
                        h->cell_start, h->dstats);
   });
@@ -381,7 +387,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (!h->forces_uniform) h->cur_f ^= 1;
   if (h->pci_active) h->cur_pci ^= 1;
   h->grid_valid = true;
-  if (h->prm.math_mode == DSL_MATH_FAST) {
+  if (!h->lsh) {
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
                          h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr);
@@ -389,8 +395,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     if (rc) return rc;
 
   }
-  if (h->c.n_ptr && h->prm.math_mode != DSL_MATH_FAST) {
-    // the sort has dropped the stale ghosts; the live count stays on the device (FAST: k_tile_list did it)
+  if (h->c.n_ptr && h->lsh) {
+    // the sort has dropped the stale ghosts; the live count stays on the device (otherwise k_tile_list did it)
     hipLaunchKernelGGL(k_set_count, dim3(1), dim3(1), 0, h->stream, h->dn, h->cell_start + h->ncell);
     HIP_TRY(h, hipGetLastError());
   }
@@ -409,6 +415,11 @@ int by_math(dsl_handle* h, Launch&& l) {
 // FAST mode uses the LDS-tiled kernels; the reference's running-mass viscosity recurrence
 // (sph_field.go:265) is order- and membership-dependent for m != 1 and stays on the
 // branching lane-per-particle kernel.
+// EXACT mode on the LDS-tiled kernels (same staging and masks, the reference's own operations and
+// order): single-domain grid runs; slab ranks and lsh_ref keep the lane-per-particle kernels.
+bool exact_tiled(const dsl_handle* h) {
+  return h->prm.math_mode == DSL_MATH_EXACT && !h->lsh && h->c.slab_axis < 0 && h->nmask != nullptr;
+}
 bool use_tiled(const dsl_handle* h) {
   if (h->prm.math_mode != DSL_MATH_FAST || h->lsh) return false;
   if (h->c.wcsph_viscosity && h->c.visc_running_mass && h->c.mass != 1.0f) return false;
@@ -440,14 +451,20 @@ int density_pass(dsl_handle* h) {
     h->masks_valid = true;  // until positions or the slot order change
     return DSL_OK;
   }
+  const bool xt = exact_tiled(h);
   int rc = timed(h, DSL_K_DENSITY, [&] {
-    by_math(h, [&](auto fast) {
-      hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
-                         neigh(h), bnd_of(h), p, h->rho, h->pterm);
-    });
+    if (xt)
+      hipLaunchKernelGGL((k_density_tiled<false, true>), dim3(persistent_grid(h, 2)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                         h->tiles, h->n_tiles, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap);
+    else
+      by_math(h, [&](auto fast) {
+        hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
+                           neigh(h), bnd_of(h), p, h->rho, h->pterm);
+      });
   });
   if (rc) return rc;
   h->dens_fresh = true;
+  if (xt) h->masks_valid = true;
   return DSL_OK;
 }
 
@@ -518,6 +535,27 @@ int force_integrate(dsl_handle* h, int part = 0) {
 #undef DSL_LAUNCH_FT3
 #undef DSL_LAUNCH_FT2
 #undef DSL_LAUNCH_FT
+    });
+  } else if (exact_tiled(h) && h->masks_valid) {
+    rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
+      dim3 g(persistent_grid(h, 2)), b(kTBlock);
+      const bool XS = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
+#define DSL_LAUNCH_FX(GG, VV, XX)                                                                                  \
+  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, false, false, true>), g, b, 0, h->stream, c, \
+                     h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, \
+                     h->dstats, h->nmask, h->cap, nullptr, bnd_of(h))
+      if (XS) {
+        if (G && V) DSL_LAUNCH_FX(true, true, true);
+        else if (G) DSL_LAUNCH_FX(true, false, true);
+        else if (V) DSL_LAUNCH_FX(false, true, true);
+        else DSL_LAUNCH_FX(false, false, true);
+      } else {
+        if (G && V) DSL_LAUNCH_FX(true, true, false);
+        else if (G) DSL_LAUNCH_FX(true, false, false);
+        else if (V) DSL_LAUNCH_FX(false, true, false);
+        else DSL_LAUNCH_FX(false, false, false);
+      }
+#undef DSL_LAUNCH_FX
     });
   } else
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
@@ -806,7 +844,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
-  if (h->prm.math_mode == DSL_MATH_FAST && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
+  if (!h->lsh && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
   for (int k = 0; k < 6 && me == hipSuccess; ++k) me = hipMemsetAsync(h->pv[0][k], 0, n * sizeof(float), h->stream);

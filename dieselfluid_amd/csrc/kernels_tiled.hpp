@@ -307,6 +307,11 @@ __device__ __forceinline__ void mask_push(unsigned int& mask, float q) {
   asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(q) : "vcc");
 }
 
+// mask = 2*mask + (a < b)
+__device__ __forceinline__ void mask_push_lt(unsigned int& mask, float a, float b) {
+  asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
+}
+
 // Staging: wave w owns rows w, w+8, ... (at most kRowsPerWave).  The loads of ALL its rows are
 // issued back to back (one record per lane and row) before anything waits, so a tile pays one
 // global-memory latency instead of one per row; rows longer than 64 records finish in a loop.
@@ -403,7 +408,15 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
 // expanded form at ~2e-6 -- inside the FAST-mode tolerance, and invisible to the cut-off
 // (a candidate that far out contributes ~1e-12).
 // ---------------------------------------------------------------------------------
-template <bool SHARE>
+// EXACT = true (DSL_MATH_EXACT): the reference's own float32 operations, one rounding each
+// (sph_field.go:155-172, std_kernel.go:33-39, vector.go:301-308), summed in the reference's order --
+// candidates cell by cell, ascending particle id inside a cell -- so the result is bit for bit the
+// oracle's.  Two phases per run: the sweep forms r^2 = (dx*dx + dy*dy) + dz*dz for every candidate and
+// pushes (r^2 < r2_thr) into the mask, r2_thr being the smallest float whose correctly rounded square root
+// is >= h, i.e. exactly the reference's `dist < h`; then the set bits are walked in ascending candidate
+// order with IEEE sqrt and divide, a handful of candidates instead of all of them.  One lane per target
+// always (sharing a target out would re-associate the sum).
+template <bool SHARE, bool EXACT = false>
 __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
                                                           const int* __restrict__ n_tiles,
                                                           const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
@@ -416,7 +429,8 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
-  if (share_wanted(n_tiles) != SHARE) return;  // (n_tiles is the base of the tile-list counters here)
+  static_assert(!(EXACT && SHARE), "the exact sum is sequential: one lane per target");
+  if (!EXACT && share_wanted(n_tiles) != SHARE) return;  // (n_tiles is the base of the tile-list counters here)
   auto load_rec = [&](int g, float* o) {
     o[0] = p.x[g];
     o[1] = p.y[g];
@@ -446,6 +460,10 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
       stage_commit<3>(m, wid, lane, recs, load_rec, [&](int slot, const float* o, bool real) {
+        if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
+          A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
+          return;
+        }
         float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
         if (real) {
           const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
@@ -481,6 +499,98 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
       const int g = m.row_gs[srow] + off;
       float acc = 0.0f, acc1 = 0.0f, self_term = 1.0f;
       unsigned int mvalid = 0u;
+      if constexpr (EXACT) {
+        if (!ovf) {
+          const int own = m.row_lds[srow] + off;
+          const float4 me = A[own];
+          const int lx = tile_target_cell(m, srow, off);
+          const int pad_rec = m.row_lds[1] - kTPad;
+          float density = 0.0f;
+          // SPHField.Density's loop body for one candidate record (sph_field.go:164-170): exactly the
+          // operations of k_density<false>; a pad record or the particle itself adds +0
+          auto add = [&](const float4& cnd, bool counts) {
+            const float dx = me.x - cnd.x, dy = me.y - cnd.y, dz = me.z - cnd.z;
+            const float dist = dsl_sqrt<false>(dist2<false>(dx, dy, dz));
+            float w = kern_F<false>(c, dist);
+            w = counts ? w : 0.0f;
+            const float mw = c.mass * w;
+            density = density + mw;
+          };
+#pragma unroll 1
+          for (int ri = 0; ri < 9; ++ri) {
+            const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
+            const int rb = m.row_lds[rr];
+            int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
+            const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            if (je - j <= 64) mvalid |= 1u << ri;
+            if (!(j < je)) nmask[(size_t)ri * mstride + g] = 0u;  // an empty run still has a (read) mask word
+            // chunks of up to 32 candidates: sweep -> mask word -> walk of its set bits, first candidate first
+            for (int chunk = 0; j < je; ++chunk, j += 32) {
+              const int jend = min(je, j + 32);
+              unsigned int mask = 0u;
+              for (int jj = j; jj < jend; jj += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const float4 cnd = A[jj + u];
+                  const float dx = me.x - cnd.x, dy = me.y - cnd.y, dz = me.z - cnd.z;
+                  mask_push_lt(mask, dist2<false>(dx, dy, dz), c.r2_thr);
+                }
+              }
+              // the sweep tests whole groups of 4: the up to 3 records behind the run belong to a cell the
+              // reference's stencil does not visit (or are pads); their bits, the lowest, are dropped
+              mask &= ~0u << ((4 - ((jend - j) & 3)) & 3);
+              if (chunk == 0) nmask[(size_t)ri * mstride + g] = mask;
+              else if (chunk == 1) nmask[(size_t)(kMaskHigh + ri) * mstride + g] = mask;
+              const int top = j + ((jend - j + 3) & ~3) - 1;  // record of bit 0
+              unsigned int mm = mask;
+              auto take = [&](bool& counts) {
+                const bool has = mm != 0u;
+                const int b = 31 - __builtin_clz(mm | 1u);  // highest set bit = earliest candidate
+                const int idx = has ? top - b : pad_rec;
+                mm &= ~(1u << b);
+                mm = has ? mm : 0u;
+                counts = has && idx != own;  // `if i != pIndex` (sph_field.go:164)
+                return idx;
+              };
+              if (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
+                bool cp, cq;
+                float4 pr = A[take(cp)];
+                bool more;
+                do {  // two candidates per trip, the next trip's record requested before the arithmetic
+                  const float4 qr = A[take(cq)];
+                  add(pr, cp);
+                  more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
+                  const bool cq2 = cq;
+                  pr = A[take(cp)];
+                  add(qr, cq2);
+                } while (more);
+              }
+            }
+          }
+          acc = density;
+        } else if (sub == 0) {
+          const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
+          for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+            if (j == g) return;
+            const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+            const float dist = dsl_sqrt<false>(dist2<false>(dx, dy, dz));
+            if (dist < c.h) {
+              const float w = kern_F<false>(c, dist);
+              acc += c.mass * w;
+            }
+          });
+        }
+        nmask[(size_t)kMaskValid * mstride + g] = mvalid;
+        if (bnd.is(g)) {
+          rho[g] = 0.0f;
+          pterm[g] = __uint_as_float(0x7fc00000u);
+          return;
+        }
+        rho[g] = acc;
+        const float pr = tait_eos<false>(c, acc, c.eos_d0_grad);
+        pterm[g] = dsl_div<false>(pr, acc * acc);
+        return;
+      }
       if (!ovf) {
         const float4 me = A[m.row_lds[srow] + off];
         // a particle whose position has gone NaN (the reference produces such next to boundary particles)
@@ -594,15 +704,20 @@ constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
 // with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
 // SLAB compiles in the multi-GPU logic (ownership, ghost tiles, split step); the single-domain
 // instantiations carry none of it.
-template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false, bool SHARE = true>
+// EXACT = true (DSL_MATH_EXACT): the reference's own float32 operations in the reference's order (runs in
+// z, y order, candidates ascending, one lane per target), IEEE sqrt and divide, bit for bit the oracle's
+// Gradient / LaplacianForce / Update; same staging, same masks (written by the EXACT density sweep).
+template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false, bool SHARE = true,
+          bool EXACT = false>
 // (Two 8-wave workgroups per CU need <= 128 VGPRs.  The headline instantiation gets there on its
 // own and schedules best unconstrained; the others are held to 4 waves/SIMD.)
-__global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && !SHARE && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
+__global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && !SHARE && !EXACT && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
     DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
     const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
     const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd) {
+  static_assert(!(EXACT && SHARE), "the exact sums are sequential: one lane per target");
   if (share_stats != nullptr && share_wanted(share_stats) != SHARE) return;
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];  // x,y,z,P/rho^2
@@ -640,7 +755,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       tile_target(m, tperm, srow0, off0);
       const int g0 = m.row_gs[srow0] + off0;
       pre_valid = nmask[(size_t)kMaskValid * mstride + g0];
-      pre_word = nmask[(size_t)4 * mstride + g0];  // the centre run: visited first, whatever the lane's mirroring
+      pre_word = nmask[(size_t)(EXACT ? 0 : 4) * mstride + g0];  // the run visited first (FAST: the centre run, whatever the lane's mirroring)
     }
     DSL_STAMP(t1b);
     DSL_STAMP_ADD(10, t1, t1b);  // first-pass mask word requests
@@ -664,7 +779,12 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // (a particle whose position has gone NaN -- the reference produces such next to boundary
             // particles -- is no one's neighbour there (dist < h is false); as a pad record it is none here
             // either, also in the runs that are walked without a mask)
-            if (real && o[0] == o[0] && o[1] == o[1] && o[2] == o[2]) {
+            if constexpr (EXACT) {  // raw values: rho itself, the reference divides by it pair by pair
+              if (real) {
+                a = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (WANT_V || WANT_XS) b = make_float4(o[4], o[5], o[6], o[7]);
+              }
+            } else if (real && o[0] == o[0] && o[1] == o[1] && o[2] == o[2]) {
               a = make_float4(o[0], o[1], o[2], o[3]);
               // 1/rho = 0 for an isolated particle (rho = 0): it only ever meets itself.  A boundary
               // particle (rho = 0 as well, P/rho^2 = NaN) is divided by as the reference does: 1/0 = +inf
@@ -710,7 +830,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           py = a.y;
           pz = a.z;
           pti_staged = a.w;
-          if (px == kFar) px = py = pz = __uint_as_float(0x7fc00000u);  // staged as a pad record: its position is NaN
+          if (!EXACT && px == kFar) px = py = pz = __uint_as_float(0x7fc00000u);  // staged as a pad record: its position is NaN
           if constexpr (WANT_V || WANT_XS) {
             const float4 b = B[own];
             vx = b.x;
@@ -763,15 +883,72 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // it works on the current ones
             struct PairRec {
               float4 a, b;
+              int idx;
             };
             auto fetch = [&](int j) {
               PairRec r;
               r.a = A[j];
               r.b = r.a;
               if constexpr (WANT_V || WANT_XS) r.b = B[j];
+              r.idx = j;
               return r;
             };
-            auto accum = [&](const PairRec& rec) {
+            const int own_rec = m.row_lds[srow] + off;
+            // EXACT: the loop bodies of SPHField.Gradient (sph_field.go:183-199), LaplacianForce (:259-266) and
+            // the build-defined sums for one candidate, operation by operation as force_sweep<false> has them;
+            // the particle itself, a pad record and a candidate at dist >= h add +0
+            auto accum_exact = [&](const PairRec& rec) {
+              const float4 a = rec.a, b = rec.b;
+              const float dx = a.x - px, dy = a.y - py, dz = a.z - pz;  // dir = x_j - x_i (sph_field.go:189)
+              const float dist = dsl_sqrt<false>(dist2<false>(dx, dy, dz));
+              const bool in = rec.idx != own_rec && dist < c.h;
+              if constexpr (WANT_XS) {
+                const float fw = kern_F<false>(c, dist);
+                const float ws = c.mass * fw;
+                const float tsx = dx * ws, tsy = dy * ws, tsz = dz * ws;
+                cohx = cohx + (in ? tsx : 0.0f);
+                cohy = cohy + (in ? tsy : 0.0f);
+                cohz = cohz + (in ? tsz : 0.0f);
+                const float wx = (c.mass / b.w) * fw;
+                const float txx = (b.x - vx) * wx, txy = (b.y - vy) * wx, txz = (b.z - vz) * wx;
+                xsx = xsx + (in ? txx : 0.0f);
+                xsy = xsy + (in ? txy : 0.0f);
+                xsz = xsz + (in ? txz : 0.0f);
+              }
+              if constexpr (WANT_G) {
+                float nx = 0.f, ny = 0.f, nz = 0.f;  // vector.go:322-331 Norm
+                if (dist != 0.0f) {
+                  nx = dx / dist;
+                  ny = dy / dist;
+                  nz = dz / dist;
+                }
+                const float sgrad = -kern_O1D<false>(c, dist);  // std_kernel.go:74-76 Grad
+                const float ggx = nx * sgrad, ggy = ny * sgrad, ggz = nz * sgrad;
+                const float F = pti_staged + a.w;
+                const float tx = ggx * F, ty = ggy * F, tz = ggz * F;
+                gx = gx + (in ? tx : 0.0f);
+                gy = gy + (in ? ty : 0.0f);
+                gz = gz + (in ? tz : 0.0f);
+              }
+              if constexpr (WANT_V) {
+                const float inv = 1.0f / b.w;
+                const float ux = (b.x - vx) * inv, uy = (b.y - vy) * inv, uz = (b.z - vz) * inv;
+                const float o2 = kern_O2D<false>(c, dist);
+                const float tx = ux * o2, ty = uy * o2, tz = uz * o2;
+                if (c.visc_running_mass) {  // sph_field.go:265: (force + t) * m
+                  const float sx = lx_ + tx, sy = ly_ + ty, sz = lz_ + tz;
+                  lx_ = in ? sx * c.mass : lx_;
+                  ly_ = in ? sy * c.mass : ly_;
+                  lz_ = in ? sz * c.mass : lz_;
+                } else {
+                  const float mx = tx * c.mass, my = ty * c.mass, mz = tz * c.mass;
+                  lx_ = lx_ + (in ? mx : 0.0f);
+                  ly_ = ly_ + (in ? my : 0.0f);
+                  lz_ = lz_ + (in ? mz : 0.0f);
+                }
+              }
+            };
+            auto accum_fast = [&](const PairRec& rec) {
               const float4 a = rec.a;
               const float dx = a.x - px, dyy = a.y - py, dzz = a.z - pz;
               float r2 = __builtin_fmaf(dzz, dzz, __builtin_fmaf(dyy, dyy, dx * dx));
@@ -808,6 +985,10 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 xsz = __builtin_fmaf(b.z, wx, xsz);
                 xw_ += wx;
               }
+            };
+            auto accum = [&](const PairRec& rec) {
+              if constexpr (EXACT) accum_exact(rec);
+              else accum_fast(rec);
             };
             const bool first_pass = !SHARED && t == tperm;  // (its mask words were requested before the staging)
             const unsigned int runs_masked =
@@ -854,9 +1035,16 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 // of ~20 VALU instructions per pair: 5.9 clocks per instruction at 4 waves per SIMD.)
                 auto take = [&]() {
                   const bool has = mm != 0u;
-                  const int idx = has ? top - __builtin_ctz(mm) : pad_rec;
-                  mm &= mm - 1u;
-                  return idx;
+                  if constexpr (EXACT) {  // highest bit = earliest candidate first: the reference's order
+                    const int b = 31 - __builtin_clz(mm | 1u);
+                    const int idx = has ? top - b : pad_rec;
+                    mm = has ? (mm & ~(1u << b)) : 0u;
+                    return idx;
+                  } else {
+                    const int idx = has ? top - __builtin_ctz(mm) : pad_rec;
+                    mm &= mm - 1u;
+                    return idx;
+                  }
                 };
                 if (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
                   // (one exit, both pairs of a trip unconditional: with an exit between a fetch and its
@@ -886,6 +1074,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               // (the centre run, the same for every mirroring, comes first: its mask word can be
               // requested before the position is known, and its walk, the longest, covers the next word's latency)
               auto run_of = [&](int s) {
+                if constexpr (EXACT) return s;  // z, y order: the reference's
                 const int ms = s == 0 ? 4 : (s <= 4 ? s - 1 : s);
                 return ((ms / 3 - 1) * sz + 1) * 3 + ((ms % 3 - 1) * sy + 1);
               };
@@ -945,6 +1134,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 xw_ += __shfl_xor(xw_, o, kWave);
               }
             }
+            if constexpr (!EXACT) {
             if constexpr (WANT_V) {
               lx_ = __builtin_fmaf(-vx, lw_, lx_);
               ly_ = __builtin_fmaf(-vy, lw_, ly_);
@@ -968,12 +1158,13 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             lx_ *= sv;
             ly_ *= sv;
             lz_ *= sv;
+            }  // !EXACT
           }
         } else {
           float accG[3] = {0.f, 0.f, 0.f}, accV[3] = {0.f, 0.f, 0.f}, accX[3] = {0.f, 0.f, 0.f},
                 accS[3] = {0.f, 0.f, 0.f};
           if constexpr (WANT_G || WANT_V || WANT_XS)
-            force_sweep<true, WANT_G, WANT_V>(c, grid_neigh(cell_start), g, pin, vin, rho, pterm, accG, accV,
+            force_sweep<!EXACT, WANT_G, WANT_V>(c, grid_neigh(cell_start), g, pin, vin, rho, pterm, accG, accV,
                                               WANT_XS ? accX : nullptr, WANT_XS ? accS : nullptr);
           cohx = accS[0];
           cohy = accS[1];
@@ -998,6 +1189,31 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             fz = fin.z[g];
           }
         }
+        if constexpr (EXACT) {  // the roundings of k_force_integrate<false> (fluid.go:164-172,146-152)
+          if constexpr (WANT_G) {
+            const float dm = rho[g] * c.mass;
+            const float tx = gx * dm, ty = gy * dm, tz = gz * dm;
+            const float sx = tx * c.pressure_sign, sy = ty * c.pressure_sign, sz = tz * c.pressure_sign;
+            fx += sx;
+            fy += sy;
+            fz += sz;
+          }
+          if constexpr (WANT_V) {
+            const float tx = lx_ * c.mu, ty = ly_ * c.mu, tz = lz_ * c.mu;
+            fx += tx;
+            fy += ty;
+            fz += tz;
+          }
+          if constexpr (WANT_XS) {
+            const float sx = cohx * c.st_kappa, sy = cohy * c.st_kappa, sz = cohz * c.st_kappa;
+            fx += sx;
+            fy += sy;
+            fz += sz;
+            xsx *= c.xsph_eps;
+            xsy *= c.xsph_eps;
+            xsz *= c.xsph_eps;
+          }
+        } else {
         if constexpr (WANT_G) {
           const float dm = rho[g] * c.mass * c.pressure_sign;
           fx = __builtin_fmaf(gx, dm, fx);
@@ -1016,6 +1232,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           xsx *= c.xsph_eps;
           xsy *= c.xsph_eps;
           xsz *= c.xsph_eps;
+        }
         }
         if constexpr (OUT == kOutIntegrate) {
           fx += c.ext[0];

@@ -22,6 +22,7 @@ struct DevConsts {
   int n;
   // kernel/std_kernel.go:20-31
   float h, hh, inv_h, inv_hh, A, B, C, W0;
+  float r2_thr;  // smallest float whose correctly rounded square root is >= h: (r2 < r2_thr) == (sqrt(r2) < h)
   float mass, inv_mass, ref_density, mu, dt, delta;
   // model/model.go:92-101
   float eos_wg, eos_gamma, eos_d0_grad;
