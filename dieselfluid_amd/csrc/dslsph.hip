@@ -709,15 +709,18 @@ void free_all(dsl_handle* h) {
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
+// (every pointer is checked by itself: a retry after a failed allocation neither leaks nor re-allocates)
 int alloc_pci(dsl_handle* h) {
-  if (h->pci[0][0]) return DSL_OK;
   for (int k = 0; k < 3; ++k)
-    if (int rc = dev_alloc(h, &h->gterm[k], (size_t)h->cap)) return rc;
+    if (!h->gterm[k])
+      if (int rc = dev_alloc(h, &h->gterm[k], (size_t)h->cap)) return rc;
   for (int k = 0; k < 3; ++k)
-    if (int rc = dev_alloc(h, &h->xsph[k], (size_t)h->cap)) return rc;
+    if (!h->xsph[k])
+      if (int rc = dev_alloc(h, &h->xsph[k], (size_t)h->cap)) return rc;
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 6; ++k)
-      if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
+      if (!h->pci[w][k])
+        if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
   return DSL_OK;
 }
 
@@ -914,8 +917,20 @@ int dsl_set_params(dsl_handle* h, const dsl_params* p) {
   if (std::memcmp(c.reset, h->c.reset, sizeof(c.reset)) != 0 && h->forces_uniform) {
     if (int rc = materialise_forces(h)) return rc;  // keep the old implicit value
   }
+  // derived per-particle state: rho scales with the mass, P/rho^2 follows the EOS constants
+  const bool mass_changed = c.mass != h->c.mass;
+  const bool eos_changed = c.eos_wg != h->c.eos_wg || c.eos_gamma != h->c.eos_gamma || c.eos_d0_grad != h->c.eos_d0_grad;
   h->prm = *p;
   h->c = c;
+  if (mass_changed) {
+    h->dens_fresh = false;  // densities (and P/rho^2) are stale: the next pass that needs them must follow a density pass
+  } else if (eos_changed && h->dens_fresh) {
+    dim3 g(grid_for(launch_n(h))), b(kBlock);
+    by_math(h, [&](auto fast) {
+      hipLaunchKernelGGL((k_pterm<decltype(fast)::value>), g, b, 0, h->stream, h->c, bnd_of(h), h->rho, h->pterm);
+    });
+    HIP_TRY(h, hipGetLastError());
+  }
   return DSL_OK;
 }
 

@@ -226,3 +226,33 @@ def test_shared_short_passes_match_the_oracle():
         assert helpers.rel_err(gv, ora.velocities(), floor=1e-2) < 5e-3
     rho = eng.download("densities")
     assert np.all(np.isfinite(rho)) and rho.max() > 1.5 * p.ref_density  # the clump really is crowded
+
+
+@pytest.mark.parametrize("math_mode", [EXACT, FAST])
+def test_set_params_refreshes_derived_state(math_mode):
+    """dsl_set_params with a new EOS constant re-derives P/rho^2 from the cached densities, and a new mass
+    marks the densities stale: the gradient pass after it equals that of an engine created with the new values."""
+    from dieselfluid_amd import scenes
+    n3 = 10
+    p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+    vel = helpers.seeded_velocities(n3 ** 3, 0.05, seed=5)
+
+    def gradient_forces(eng):
+        eng.gradient_pressure_force()
+        return eng.download("forces")
+
+    for field, factor in (("eos_gamma", 0.5), ("mass", 1.25)):
+        q, _ = scenes.dambreak_scene(n3, math_mode=math_mode, positions=False)
+        setattr(q, field, getattr(q, field) * factor)
+        late, fresh = _engine(p), _engine(q)
+        for eng in (late, fresh):
+            eng.upload("positions", pos)
+            eng.upload("velocities", vel)
+            eng.nn()
+            eng.density_all()
+        late.set_params(q)
+        if field == "mass":  # densities scale with the mass: they have to be taken again
+            late.density_all()
+        fa, fb = gradient_forces(late), gradient_forces(fresh)
+        assert np.array_equal(fa, fb), field
+        late.close(); fresh.close()
