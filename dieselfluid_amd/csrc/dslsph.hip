@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -66,6 +67,7 @@ struct dsl_handle {
   int *bucket_of = nullptr, *lsh_table = nullptr, *lsh_len = nullptr, *lsh_samples = nullptr;
   TileGrid tg{};
   int *tiles = nullptr, *n_tiles = nullptr;
+  int *tile_desc_of = nullptr, *tile_desc = nullptr;  // per list entry: index of the tile's table; the tables (k_tile_desc)
   // SoA state
   float* pv[2][6] = {};
   int* ids[2] = {};
@@ -211,7 +213,8 @@ inline int launch_n(const dsl_handle* h) { return h->c.n_ptr ? h->cap : h->n; }
 
 template <class T>
 int dev_alloc(dsl_handle* h, T** p, size_t count) {
-  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  // (16 bytes of padding: the staging quads of the tiled kernels read up to three elements past a row)
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 16);
   if (e != hipSuccess) return fail(h, DSL_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   return DSL_OK;
 }
@@ -390,7 +393,10 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (!h->lsh) {
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
-                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr);
+                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr, h->tile_desc_of);
+      // the tables of the non-empty tiles, once per build for every kernel that sweeps tiles
+      hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, h->c, h->tg,
+                         h->cell_start, h->tiles, h->n_tiles, h->tile_desc);
     });
     if (rc) return rc;
 
@@ -440,8 +446,8 @@ int density_pass(dsl_handle* h) {
     // returns at once (kernels_tiled.hpp: share_wanted)
     int rc = timed(h, DSL_K_DENSITY, [&] {
 #define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
-  hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, \
-                     h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap)
+  hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, \
+                     h->tile_desc, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap)
       DSL_LAUNCH_DENSITY(k_density_tiled<false>);
       DSL_LAUNCH_DENSITY(k_density_tiled<true>);
 #undef DSL_LAUNCH_DENSITY
@@ -455,7 +461,7 @@ int density_pass(dsl_handle* h) {
   int rc = timed(h, DSL_K_DENSITY, [&] {
     if (xt)
       hipLaunchKernelGGL((k_density_tiled<false, true>), dim3(persistent_grid(h, 2)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                         h->tiles, h->n_tiles, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap);
+                         h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap);
     else
       by_math(h, [&](auto fast) {
         hipLaunchKernelGGL((k_density<decltype(fast)::value>), dim3(grid_for(launch_n(h))), dim3(kBlock), 0, h->stream, c,
@@ -482,9 +488,9 @@ int force_integrate(dsl_handle* h, int part = 0) {
   // step's band / interior launch) plus 3 = ghost-only tiles, visited by one launch per step
   const bool slab = c.slab_axis >= 0;
   const int la = !slab ? 0 : (part == 0 ? 4 : part);
-  const int* tiles = h->tiles + (size_t)la * h->tg.ntiles;
+  const int* tiles = h->tile_desc_of + (size_t)la * h->tg.ntiles;
   const int* n_tiles = h->n_tiles + la;
-  const int* gtiles = (slab && part != 2) ? h->tiles + (size_t)3 * h->tg.ntiles : nullptr;
+  const int* gtiles = (slab && part != 2) ? h->tile_desc_of + (size_t)3 * h->tg.ntiles : nullptr;
   const int* n_gtiles = h->n_tiles + 3;
   CSoa3 p = cpos(h), v = cvel(h), f = cfrc(h);
   const int o = h->cur_pv ^ 1;
@@ -504,7 +510,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
       dim3 g(gsz), b(kTBlock);
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
-                     h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
+                     h->tg, tiles, n_tiles, gtiles, n_gtiles, h->tile_desc, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
                      po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, (XX) ? nullptr : h->n_tiles, bnd_of(h))
   // (the XSPH / cohesion variant exists as the pass-sharing instantiation only; of the other two
   // the device picks: kernels_tiled.hpp, share_wanted)
@@ -542,7 +548,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
       const bool XS = c.xsph_eps != 0.0f || c.st_kappa != 0.0f;
 #define DSL_LAUNCH_FX(GG, VV, XX)                                                                                  \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, false, false, true>), g, b, 0, h->stream, c, \
-                     h->tg, tiles, n_tiles, gtiles, n_gtiles, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, \
+                     h->tg, tiles, n_tiles, gtiles, n_gtiles, h->tile_desc, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, \
                      h->dstats, h->nmask, h->cap, nullptr, bnd_of(h))
       if (XS) {
         if (G && V) DSL_LAUNCH_FX(true, true, true);
@@ -692,6 +698,8 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->dn);
   (void)hipFree(h->pack_counts);
   (void)hipFree(h->tiles);
+  (void)hipFree(h->tile_desc_of);
+  (void)hipFree(h->tile_desc);
   (void)hipFree(h->n_tiles);
   (void)hipFree(h->hashv);
   (void)hipFree(h->bucket_of);
@@ -847,6 +855,10 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
+  // a non-empty tile holds a particle: at most min(tiles, capacity) tables (1.5 KB each)
+  if ((rc = dev_alloc(h, &h->tile_desc_of, (size_t)kTileLists * h->tg.ntiles)) ||
+      (rc = dev_alloc(h, &h->tile_desc, (size_t)std::min(h->tg.ntiles, h->cap) * kMetaInts)))
+    return bail(rc);
   if (!h->lsh && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
   hipError_t me = hipSuccess;
@@ -888,6 +900,8 @@ int dsl_destroy(dsl_handle* h) {
                  "%llu, barrier %llu) target-prologue %llu sweep %llu | density: setup %llu staging %llu (load issue %llu, "
                  "wait+LDS %llu) sweep %llu\n",
                  d[0], d[1], d[10], d[8], d[9], d[11], d[2], d[3], d[4], d[5], d[12], d[13], d[6]);
+    std::fprintf(stderr, "[dsl diag] density staging: commit %llu, row table + barrier %llu, scan + record requests %llu\n", d[14],
+                 d[15], d[16]);
   }
 #endif
   (void)dsl_slab_detach(h);
@@ -1398,17 +1412,17 @@ int pci_begin_step(dsl_handle* h) {
     int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45 (+ cohesion, XSPH sums)
       if (XS)
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
-                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
                            h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
       else
         hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
-                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
+                           dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
                            h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
     });
     if (rc) return rc;
     rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
       hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
-                         dim3(kTBlock), 0, h->stream, c, h->tg, h->tiles, h->n_tiles, nullptr, nullptr, h->cell_start, p, v, h->rho,
+                         dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
                          h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
     });
     if (rc) return rc;
@@ -1437,7 +1451,7 @@ int pci_iterate(dsl_handle* h) {
   rc = timed(h, DSL_K_PCI_DENSITY, [&] {
     if (tiled)
       hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                         h->tiles, h->n_tiles, h->cell_start, bnd_of(h), p, cpp, h->press, h->dstats);
+                         h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), p, cpp, h->press, h->dstats);
     else
       by_math(h, [&](auto fast) {
         hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), bnd_of(h), p, cpp,

@@ -49,7 +49,15 @@ struct TileMeta {
   int cellS[kTRows * (kTH + 1)];  // per row: offset of each of its 6 cells (+ end) inside the row
   int tprefix[kTB * kTB + 1];     // prefix of target counts over the 16 interior rows
   int overflow;
+  int tile;                       // the tile's id in the tile grid
+  int pad_[4];                    // 384 ints: a whole number of 16-byte pieces
 };
+// A tile's table is built ONCE per neighbour build, by k_tile_desc, into a global array of these
+// (one per non-empty tile, in the order of tile list 0); the sweeping kernels copy it into LDS, one
+// dword per lane, one tile ahead of its use.  (Each kernel used to derive it again for every tile it
+// visited -- seven dependent loads per row, a scan and two more barriers in front of every staging.)
+constexpr int kMetaInts = 384;
+static_assert(sizeof(TileMeta) == kMetaInts * sizeof(int), "TileMeta is copied as kMetaInts dwords");
 
 struct TileGrid {
   int tnx, tny, tnz, ntiles;
@@ -73,9 +81,12 @@ __device__ unsigned long long g_diag[32];
 // pass just marks those for removal), and for the split force pass [1] the owning tiles that
 // contain band cell layers and [2] those that contain other layers (a tile straddling the
 // limit is in both).
+// desc_of: for every entry of the lists 1.. the position of its tile in list 0, i.e. the index of
+// its descriptor (k_tile_desc); list 0's own entries are their own positions.
 __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                       int* __restrict__ tiles, int* __restrict__ n_tiles,
-                                                      int* __restrict__ short_pass_tiles, int* __restrict__ n_live) {
+                                                      int* __restrict__ short_pass_tiles, int* __restrict__ n_live,
+                                                      int* __restrict__ desc_of) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
   // slab mode: the sort has dropped the stale ghosts; the live count (kept on the device) is the
   // start of the pseudo cell behind the last one.  Nothing in this launch reads the count.
@@ -108,6 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
     if (sp != 0ull && lane == 0) atomicAdd(short_pass_tiles, __builtin_popcountll(sp));
   }
   // one atomic per wave and list (same-address atomics serialise)
+  int pos0 = 0;
 #pragma unroll
   for (int l = 0; l < kTileLists; ++l) {
     const bool in = l == 0 ? cnt > 0 : (l == 1 ? in_band : (l == 2 ? in_inner : (l == 3 ? ghosts : owning)));
@@ -117,7 +129,12 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
     int base = 0;
     if (lane == leader) base = atomicAdd(n_tiles + l, __builtin_popcountll(m));
     base = __shfl(base, leader, kWave);
-    if (in) tiles[(size_t)l * tg.ntiles + base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+    if (in) {
+      const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (l == 0) pos0 = pos;
+      tiles[(size_t)l * tg.ntiles + pos] = t;
+      desc_of[(size_t)l * tg.ntiles + pos] = pos0;
+    }
   }
 }
 
@@ -196,6 +213,37 @@ __device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& t
   tile_setup_commit(r, m);
 }
 
+// One wave per non-empty tile (tile list 0): the tile's table, written where the sweeping kernels
+// pick it up.  ~31k tiles x 1.5 KB at 16M particles.
+__global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
+                                                     const int* __restrict__ tiles, const int* __restrict__ n_tiles,
+                                                     int* __restrict__ desc) {
+  __shared__ TileMeta m;
+  const int n = *n_tiles;
+  for (int item = blockIdx.x; item < n; item += gridDim.x) {
+    const int tile = tiles[item];
+    tile_setup(c, tg, tile, cell_start, m);
+    if (threadIdx.x == 0) m.tile = tile;
+    __syncthreads();
+    const int* src = reinterpret_cast<const int*>(&m);
+    int* out = desc + (size_t)item * kMetaInts;
+#pragma unroll
+    for (int k = 0; k < kMetaInts / kWave; ++k) out[k * kWave + threadIdx.x] = src[k * kWave + threadIdx.x];
+    __syncthreads();
+  }
+}
+
+// the copy of a tile's table into LDS, in two halves: the request (one dword per lane of the first six
+// waves, nothing waits) and, once it has landed, the LDS write; a barrier makes it visible
+__device__ __forceinline__ int tile_meta_request(const int* __restrict__ desc, int desc_index) {
+  const int tid = threadIdx.x;
+  return tid < kMetaInts ? desc[(size_t)desc_index * kMetaInts + tid] : 0;
+}
+__device__ __forceinline__ void tile_meta_store(TileMeta& m, int word) {
+  const int tid = threadIdx.x;
+  if (tid < kMetaInts) reinterpret_cast<int*>(&m)[tid] = word;
+}
+
 // target index inside the tile -> interior row id (0..15), staged row, offset inside the row
 __device__ __forceinline__ void tile_target(const TileMeta& m, int t, int& srow, int& off) {
   int ir = 0;  // largest interior row with tprefix[ir] <= t: binary search over the 16 rows
@@ -267,22 +315,23 @@ struct TileWalk {
 // The walk with the tile index fetched one tile ahead: the list entry of the tile after next is
 // requested while the next tile is being set up, so that no wave ever sits out a memory latency for a
 // list entry between a barrier and the loads that depend on it (it did: ~11k clocks per tile).
+// It hands out descriptor indices (k_tile_desc): `desc_of` is the list's companion written by k_tile_list.
 struct TileFeed {
   TileWalk walk;
-  const int* __restrict__ list;
+  const int* __restrict__ desc_of;
   bool have_next;
   int next;
-  __device__ __forceinline__ TileFeed(const int* __restrict__ l, int n_tiles) : walk(n_tiles), list(l) {
+  __device__ __forceinline__ TileFeed(const int* __restrict__ d, int n_tiles) : walk(n_tiles), desc_of(d) {
     int item;
     have_next = walk.next(item);
-    next = have_next ? list[item] : 0;
+    next = have_next ? desc_of[item] : 0;
   }
-  __device__ __forceinline__ bool pop(int& tile) {
+  __device__ __forceinline__ bool pop(int& desc_index) {
     if (!have_next) return false;
-    tile = next;
+    desc_index = next;
     int item;
     have_next = walk.next(item);
-    if (have_next) next = list[item];
+    if (have_next) next = desc_of[item];
     return true;
   }
 };
@@ -312,51 +361,69 @@ __device__ __forceinline__ void mask_push_lt(unsigned int& mask, float a, float 
   asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
 }
 
-// Staging: wave w owns rows w, w+8, ... (at most kRowsPerWave).  The loads of ALL its rows are
-// issued back to back (one record per lane and row) before anything waits, so a tile pays one
-// global-memory latency instead of one per row; rows longer than 64 records finish in a loop.
-constexpr int kRowsPerWave = (kTRows + kTBlock / kWave - 1) / (kTBlock / kWave);  // 5
+// Staging.  The vector-memory path takes a wave instruction every 16 clocks whatever its width, and a
+// tile used to cost it 120 (density) or 320 (force) one-dword loads.  Now lane t owns the four consecutive
+// records 4k .. 4k+3 of staged row r (r = t / 14, k = t % 14: 36 rows x 14 quads on 504 lanes, 56 records
+// per row in one go, longer rows finish in a loop): ONE unaligned dwordx4 load per source array brings its
+// four values, 3 or 8 loads per lane and tile, and the lane writes its four records as whole float4s.
+// A quad may read up to three elements past its row (the next row's, or the padding behind the arrays);
+// they are never stored.
+constexpr int kQuadsPerRow = 14;
+static_assert(kTRows * kQuadsPerRow <= kTBlock, "one quad per lane");
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 load4u(const float* __restrict__ p) {
+  const f4u v = *reinterpret_cast<const f4u*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float f4_at(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 template <int NF>
 struct StageRegs {
-  float v[kRowsPerWave][NF];
+  float4 v[NF];  // v[a] = elements g .. g+3 of source array a
 };
-// issue: one record per lane and row into registers; nothing waits here.  Needs row_gs / row_len only.
-template <int NF, class Load>
-__device__ __forceinline__ void stage_issue(const TileMeta& m, int wid, int lane, Load&& load, StageRegs<NF>& sr) {
-#pragma unroll
-  for (int k = 0; k < kRowsPerWave; ++k) {
-    const int r = wid + k * (kTBlock / kWave);
-    if (r < kTRows && lane < m.row_len[r]) load(m.row_gs[r] + lane, sr.v[k]);
-  }
+// issue: nothing waits here.  Needs row_gs / row_len only.  load4(g, out[NF]): the quad loads at slot g.
+template <int NF, class Load4>
+__device__ __forceinline__ void stage_issue(const TileMeta& m, Load4&& load4, StageRegs<NF>& sr) {
+  const int t = threadIdx.x, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
+  if (r < kTRows && 4 * k < m.row_len[r]) load4(m.row_gs[r] + 4 * k, sr.v);
 }
-// commit: registers -> LDS records, the rest of rows longer than 64, the pad records
-template <int NF, class Load, class Store>
-__device__ __forceinline__ void stage_commit(const TileMeta& m, int wid, int lane, const StageRegs<NF>& sr, Load&& load,
-                                             Store&& store) {
+// commit: registers -> LDS records, the rest of rows longer than 56, the pad records.
+// load1(g, out[NF]): one record; store(slot, rec[NF], real)
+template <int NF, class Load1, class Store>
+__device__ __forceinline__ void stage_commit(const TileMeta& m, const StageRegs<NF>& sr, Load1&& load1, Store&& store) {
+  const int t = threadIdx.x, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
+  if (r >= kTRows) return;
+  const int len = m.row_len[r], ls = m.row_lds[r];
 #pragma unroll
-  for (int k = 0; k < kRowsPerWave; ++k) {
-    const int r = wid + k * (kTBlock / kWave);
-    if (r >= kTRows) continue;
-    const int len = m.row_len[r], ls = m.row_lds[r];
-    if (lane < len) store(ls + lane, sr.v[k], true);
-    for (int i = lane + kWave; i < len; i += kWave) {  // rare: more than 64 particles in the row
-      float t[NF];
-      load(m.row_gs[r] + i, t);
-      store(ls + i, t, true);
+  for (int i = 0; i < 4; ++i) {
+    if (4 * k + i < len) {
+      float rec[NF];
+#pragma unroll
+      for (int a = 0; a < NF; ++a) rec[a] = f4_at(sr.v[a], i);
+      store(ls + 4 * k + i, rec, true);
     }
-    const int npad = m.row_lds[r + 1] - ls - len;
-    if (lane < npad) store(ls + len + lane, sr.v[k], false);
+  }
+  for (int i = 4 * kQuadsPerRow + k; i < len; i += kQuadsPerRow) {  // rare: more than 56 particles in the row
+    float rec[NF];
+    load1(m.row_gs[r] + i, rec);
+    store(ls + i, rec, true);
+  }
+  const int npad = m.row_lds[r + 1] - ls - len;
+  if (k < npad) {
+    float rec[NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) rec[a] = 0.0f;
+    store(ls + len + k, rec, false);
   }
 }
-template <int NF, class Load, class Store>
-__device__ __forceinline__ void stage_rows(const TileMeta& m, int wid, int lane, Load&& load, Store&& store) {
+template <int NF, class Load4, class Load1, class Store>
+__device__ __forceinline__ void stage_rows(const TileMeta& m, Load4&& load4, Load1&& load1, Store&& store) {
   StageRegs<NF> sr;
   DSL_STAMP(s0);
-  stage_issue<NF>(m, wid, lane, load, sr);
+  stage_issue<NF>(m, load4, sr);
   DSL_STAMP(s1);
   DSL_STAMP_ADD(NF == 8 ? 8 : 12, s0, s1);  // staging: load issue
-  stage_commit<NF>(m, wid, lane, sr, load, store);
+  stage_commit<NF>(m, sr, load1, store);
   DSL_STAMP(s2);
   DSL_STAMP_ADD(NF == 8 ? 9 : 13, s1, s2);  // staging: wait for the data + LDS writes
 }
@@ -417,18 +484,17 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
 // order with IEEE sqrt and divide, a handful of candidates instead of all of them.  One lane per target
 // always (sharing a target out would re-associate the sum).
 template <bool SHARE, bool EXACT = false>
-__global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
-                                                          const int* __restrict__ n_tiles,
+__global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+                                                          const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                           const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
                                                           float* __restrict__ rho, float* __restrict__ pterm,
                                                           unsigned int* __restrict__ nmask, int mstride) {
   // Tiles are pipelined across the loop: while tile T is swept, the records of tile T+1 are on their
-  // way from HBM into registers (15 per lane) and the row table of tile T+2 likewise (7 per lane), so a
-  // tile's set-up and staging cost two barriers and some LDS writes instead of two memory round trips
-  // (per-phase clocks before: sweep 45 %, staging 35 %, set-up 20 % of a tile's life; profiles/r02_*).
+  // way from HBM into registers (12 per lane) and the table of tile T+2 likewise (one dword per lane), so a
+  // tile's staging costs two barriers and some LDS writes instead of memory round trips.
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
   static_assert(!(EXACT && SHARE), "the exact sum is sequential: one lane per target");
   if (!EXACT && share_wanted(n_tiles) != SHARE) return;  // (n_tiles is the base of the tile-list counters here)
   auto load_rec = [&](int g, float* o) {
@@ -436,30 +502,36 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     o[1] = p.y[g];
     o[2] = p.z[g];
   };
-  TileFeed feed(tiles, *n_tiles);
-  TileSetupRegs rows;   // row table of the tile after the one whose records are in flight
+  auto load_quad = [&](int g, float4* o) {
+    o[0] = load4u(p.x + g);
+    o[1] = load4u(p.y + g);
+    o[2] = load4u(p.z + g);
+  };
+  TileFeed feed(desc_of, *n_tiles);
+  int table_word = 0;   // a dword of the table of the tile after the one whose records are in flight
   StageRegs<3> recs;    // records of the next tile to be swept
-  int tile = 0, tile_next = 0, tile_after = 0;
-  if (!feed.pop(tile)) return;
-  tile_setup_load(c, tg, tile, cell_start, rows);
-  tile_setup_commit(rows, metas[0]);
-  stage_issue<3>(metas[0], wid, lane, load_rec, recs);
-  bool have_next = feed.pop(tile_next);
-  if (have_next) tile_setup_load(c, tg, tile_next, cell_start, rows);
+  int di = 0, di_next = 0, di_after = 0;
+  if (!feed.pop(di)) return;
+  tile_meta_store(metas[0], tile_meta_request(desc, di));
+  __syncthreads();
+  stage_issue<3>(metas[0], load_quad, recs);
+  bool have_next = feed.pop(di_next);
+  if (have_next) table_word = tile_meta_request(desc, di_next);
   for (int cur = 0;; cur ^= 1) {
     TileMeta& m = metas[cur];
     TileMeta& mn = metas[cur ^ 1];
     DSL_STAMP(d0);
-    __syncthreads();  // the previous tile's sweep is over: its LDS records and the other row table are free
+    __syncthreads();  // the previous tile's sweep is over: its LDS records and the other table are free
     DSL_STAMP(d1);
     DSL_STAMP_ADD(4, d0, d1);
     const bool ovf = m.overflow != 0;
     // tile centre in world coordinates
+    const int tile = m.tile;
     const float ox = c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
     const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
     const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
-      stage_commit<3>(m, wid, lane, recs, load_rec, [&](int slot, const float* o, bool real) {
+      stage_commit<3>(m, recs, load_rec, [&](int slot, const float* o, bool real) {
         if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
           A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
           return;
@@ -472,17 +544,14 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
         A[slot] = v;
       });
     }
-    if (have_next) tile_setup_raw(rows, mn);
+    if (have_next) tile_meta_store(mn, table_word);
     __syncthreads();
     bool have_after = false;
     if (have_next) {
-      // wave 0 finishes the next tile's table (read again only behind the next barrier) while every
-      // wave requests that tile's records (which need row_gs / row_len only) ...
-      if (wid == 0) tile_setup_scan(mn);
-      stage_issue<3>(mn, wid, lane, load_rec, recs);
-      // ... and the row table of the tile after it
-      have_after = feed.pop(tile_after);
-      if (have_after) tile_setup_load(c, tg, tile_after, cell_start, rows);
+      // every wave requests the next tile's records and its share of the table of the tile after it
+      stage_issue<3>(mn, load_quad, recs);
+      have_after = feed.pop(di_after);
+      if (have_after) table_word = tile_meta_request(desc, di_after);
     }
     DSL_STAMP(d2);
     DSL_STAMP_ADD(5, d1, d2);
@@ -603,9 +672,12 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
         auto sweep_run = [&](int ri, int rr) {
           const int rb = m.row_lds[rr];
           int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-          const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+          int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
           if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
           unsigned int mask = 0u;
+#ifdef DSL_DIAG_NO_SWEEP  // timing-only build: the per-tile fixed cost (set-up + staging + epilogue)
+          je = j;
+#endif
           // q = clamp(1 - r^2/h^2), r^2 = |xi|^2 + |xj|^2 - 2 xi.xj, with everything but the three
           // products folded into the staged w_j = -|xj|^2/h^2 and the per-target constants
           auto test4 = [&](int jj) {
@@ -685,8 +757,7 @@ __global__ __launch_bounds__(kTBlock) void k_density_tiled(DevConsts c, TileGrid
     DSL_STAMP(d3);
     DSL_STAMP_ADD(6, d2, d3);
     if (!have_next) break;
-    tile = tile_next;
-    tile_next = tile_after;
+    di_next = di_after;
     have_next = have_after;
   }
 }
@@ -712,36 +783,39 @@ template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = fals
 // (Two 8-wave workgroups per CU need <= 128 VGPRs.  The headline instantiation gets there on its
 // own and schedules best unconstrained; the others are held to 4 waves/SIMD.)
 __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && !SHARE && !EXACT && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
-    DevConsts c, TileGrid tg, const int* __restrict__ tiles, const int* __restrict__ n_tiles,
-    const int* __restrict__ ghost_tiles, const int* __restrict__ n_ghost_tiles,
+    DevConsts c, TileGrid tg, const int* __restrict__ desc_of, const int* __restrict__ n_tiles,
+    const int* __restrict__ ghost_desc_of, const int* __restrict__ n_ghost_tiles, const int* __restrict__ desc,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
     const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd) {
   static_assert(!(EXACT && SHARE), "the exact sums are sequential: one lane per target");
   if (share_stats != nullptr && share_wanted(share_stats) != SHARE) return;
-  __shared__ TileMeta m;
+  __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];  // x,y,z,P/rho^2
   __shared__ float4 B[kTCap];  // vx,vy,vz,1/rho
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
   unsigned int vbits = 0u, fbits = 0u;  // max|v|, max|F| of this lane over all its tiles
   // SLAB: after the tiles with owned cell layers, the ghost-only tiles (second list, walked the same
   // XCD-chunked way so that their small cost is spread evenly): nothing is staged for those, their
   // targets are just marked for removal (a particle that float rounding puts on the owned side of
   // the plane after all takes the global-memory sweep).
-  const int nphase = (SLAB && ghost_tiles != nullptr) ? 2 : 1;
+  const int nphase = (SLAB && ghost_desc_of != nullptr) ? 2 : 1;
   for (int phase = 0; phase < nphase; ++phase) {
   const bool ghost_tile = phase == 1;
-  const int* __restrict__ list = ghost_tile ? ghost_tiles : tiles;
-  TileFeed feed(list, ghost_tile ? *n_ghost_tiles : *n_tiles);
-  TileSetupRegs next_rows;  // the NEXT tile's row loads travel under the current tile's sweep
-  int tile = 0;
-  bool have = feed.pop(tile);
-  if (have) tile_setup_load(c, tg, tile, cell_start, next_rows);
-  while (have) {
+  TileFeed feed(ghost_tile ? ghost_desc_of : desc_of, ghost_tile ? *n_ghost_tiles : *n_tiles);
+  // The NEXT tile's table (k_tile_desc) travels, one dword per lane, under the current tile's staging and
+  // is put into the other LDS copy behind it: a tile starts with ONE barrier and its table in place.
+  int di = 0;
+  bool have = feed.pop(di);
+  if (phase == 1) __syncthreads();  // (the first phase's last sweep may still be reading its table)
+  if (have) tile_meta_store(metas[0], tile_meta_request(desc, di));
+  for (int cur = 0; have; cur ^= 1) {
+    TileMeta& m = metas[cur];
     DSL_STAMP(t0);
-    __syncthreads();
-    tile_setup_commit(next_rows, m);
-    have = feed.pop(tile);
+    __syncthreads();  // the previous tile's sweep is over, this tile's table is visible
+    have = feed.pop(di);
+    int table_word = 0;
+    if (have) table_word = tile_meta_request(desc, di);
     DSL_STAMP(t1);
     DSL_STAMP_ADD(0, t0, t1);
     const bool ovf = m.overflow != 0;
@@ -761,7 +835,21 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     DSL_STAMP_ADD(10, t1, t1b);  // first-pass mask word requests
     if (!nolds) {
       stage_rows<8>(
-          m, wid, lane,
+          m,
+          [&](int g, float4* o) {
+            o[0] = load4u(pin.x + g);
+            o[1] = load4u(pin.y + g);
+            o[2] = load4u(pin.z + g);
+            o[3] = (WANT_G || bnd.ids != nullptr) ? load4u(pterm + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (WANT_V || WANT_XS) {
+              o[4] = load4u(vin.x + g);
+              o[5] = load4u(vin.y + g);
+              o[6] = load4u(vin.z + g);
+              o[7] = load4u(rho + g);
+            } else {
+              o[4] = o[5] = o[6] = o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+          },
           [&](int g, float* o) {
             o[0] = pin.x[g];
             o[1] = pin.y[g];
@@ -797,10 +885,10 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           });
     }
     DSL_STAMP(t1c);
+    if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
     __syncthreads();
     DSL_STAMP(t1d);
     DSL_STAMP_ADD(11, t1c, t1d);  // barrier behind the staging
-    if (have) tile_setup_load(c, tg, tile, cell_start, next_rows);
     DSL_STAMP(t2);
     DSL_STAMP_ADD(1, t1, t2);
     const int ntarg = m.tprefix[kTB * kTB];
@@ -1302,38 +1390,49 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
 // (the reference never re-synchronises the predictor, so it may) falls back to the
 // global-memory sweep.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ tiles,
-                                                              const int* __restrict__ n_tiles,
+__global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+                                                              const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                               const int* __restrict__ cell_start, Bnd bnd, CSoa3 p, CSoa3 pp,
                                                               float* __restrict__ press, DevStats* stats) {
   if (stats->pci_done) return;
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];
-  const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
   unsigned int ebits = 0u;
-  TileWalk walk(*n_tiles);
-  int item;
-  while (walk.next(item)) {
-    const int tile = tiles[item];
+  TileFeed feed(desc_of, *n_tiles);
+  int di;
+  while (feed.pop(di)) {
+    const int table_word = tile_meta_request(desc, di);
     __syncthreads();
-    tile_setup(c, tg, tile, cell_start, m);
+    tile_meta_store(m, table_word);
+    __syncthreads();
+    const int tile = m.tile;
     const bool ovf = m.overflow != 0;
     const int tx = tile % tg.tnx, ty = (tile / tg.tnx) % tg.tny, tz = tile / (tg.tnx * tg.tny);
     const float ox = c.gmin[0] + (tx * kTB + 0.5f * kTB) * c.h;
     const float oy = c.gmin[1] + (ty * kTB + 0.5f * kTB) * c.h;
     const float oz = c.gmin[2] + (tz * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
-      for (int r = wid; r < kTRows; r += kTBlock / kWave) {
-        const int gs = m.row_gs[r], len = m.row_len[r], ls = m.row_lds[r];
-        for (int i = lane; i < len + kTPad; i += kWave) {
-          float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
-          if (i < len) {  // records as in k_density_tiled: tile-relative x, y, z and w = -|x|^2/h^2
-            const float x = p.x[gs + i] - ox, y = p.y[gs + i] - oy, z = p.z[gs + i] - oz;
-            v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-          }
-          A[ls + i] = v;
-        }
-      }
+      stage_rows<3>(
+          m,
+          [&](int g, float4* o) {
+            o[0] = load4u(p.x + g);
+            o[1] = load4u(p.y + g);
+            o[2] = load4u(p.z + g);
+          },
+          [&](int g, float* o) {
+            o[0] = p.x[g];
+            o[1] = p.y[g];
+            o[2] = p.z[g];
+          },
+          [&](int slot, const float* o, bool real) {
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+            if (real) {  // records as in k_density_tiled: tile-relative x, y, z and w = -|x|^2/h^2
+              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+            }
+            A[slot] = v;
+          });
     }
     __syncthreads();
     const int ntarg = m.tprefix[kTB * kTB];
