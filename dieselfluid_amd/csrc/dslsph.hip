@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -325,9 +326,9 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   h->masks_valid = false;  // slot order changes
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
-  HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+  // (the histogram and the "cells to order" bitmap are clean: zeroed at creation, and again by
+  // k_scan_apply / k_tile_list of the previous build)
   const bool ordered = !h->prm.sort_unordered;
-  if (ordered) HIP_TRY(h, hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream));
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                        ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered);
@@ -393,7 +394,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   if (!h->lsh) {
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
-                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr, h->tile_desc_of);
+                         h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr, h->tile_desc_of,
+                         h->unordered, h->ncell_pad / 32);
       // the tables of the non-empty tiles, once per build for every kernel that sweeps tiles
       hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, h->c, h->tg,
                          h->cell_start, h->tiles, h->n_tiles, h->tile_desc);
@@ -448,7 +450,7 @@ int density_pass(dsl_handle* h) {
 #define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
   hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, \
                      h->tile_desc, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap)
-      DSL_LAUNCH_DENSITY(k_density_tiled<false>);
+      if (c.slab_axis < 0) DSL_LAUNCH_DENSITY(k_density_tiled<false>);
       DSL_LAUNCH_DENSITY(k_density_tiled<true>);
 #undef DSL_LAUNCH_DENSITY
     });
@@ -511,12 +513,12 @@ int force_integrate(dsl_handle* h, int part = 0) {
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->tile_desc, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
-                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, (XX) ? nullptr : h->n_tiles, bnd_of(h))
-  // (the XSPH / cohesion variant exists as the pass-sharing instantiation only; of the other two
-  // the device picks: kernels_tiled.hpp, share_wanted)
+                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, ((XX) || (SS)) ? nullptr : h->n_tiles, bnd_of(h))
+  // (the XSPH / cohesion variant and the slab variant -- a slab always has half-empty ghost tiles -- exist
+  // as the pass-sharing instantiation only; of the other two the device picks: kernels_tiled.hpp, share_wanted)
 #define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                        \
   do {                                                                        \
-    if (XX) DSL_LAUNCH_FT4(GG, VV, XX, SS, true);                             \
+    if ((XX) || (SS)) DSL_LAUNCH_FT4(GG, VV, XX, SS, true);                   \
     else {                                                                    \
       DSL_LAUNCH_FT4(GG, VV, false, SS, false);                               \
       DSL_LAUNCH_FT4(GG, VV, false, SS, true);                                \
@@ -835,6 +837,12 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 16)) ||
       (rc = dev_alloc(h, &h->pack_counts, (size_t)4 * ((n + kPackChunk - 1) / kPackChunk))))
     return bail(rc);
+  // the sort keeps these two clean between builds (k_scan_apply, k_tile_list)
+  if (hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream) != hipSuccess ||
+      hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream) != hipSuccess) {
+    h->err = "hipMemsetAsync failed";
+    return bail(DSL_ERR_DEVICE);
+  }
   h->lsh = params->neigh_mode == DSL_NEIGH_LSH_REF;
   if (h->lsh) {
     const int B = params->lsh_buckets;
@@ -1882,6 +1890,12 @@ int dsl_slab_detach(dsl_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   SlabLink* L = h->link;
   if (L->comm_stream) (void)hipStreamSynchronize(L->comm_stream);
+  if (std::getenv("DSL_SLAB_GRAPH_DEBUG"))
+    std::fprintf(stderr, "[dsl] slab link: %lld steps, %lld graph captures; host seconds: launches %.4f, RCCL post %.4f, events/waits %.4f\n",
+                 (long long)L->steps, (long long)L->captures, L->host_seg_s, L->host_post_s, L->host_sync_s);
+  for (auto& per_segment : L->seg)
+    for (SegGraph& g : per_segment)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (int k = 0; k < 2; ++k) {
     (void)hipFree(L->send[k]);
     (void)hipFree(L->recv[k]);
@@ -1919,6 +1933,11 @@ int dsl_slab_attach(dsl_handle* h, dsl_comm* comm, int lo_rank, int hi_rank, flo
   L->max_full = 2 * cap_full;  // room for the re-plan to grow the messages (the same on every rank)
   L->max_x = 2 * cap_xonly;
   L->overlap = overlap != 0 && (lo_rank >= 0 || hi_rank >= 0);
+  // (measured on MI355X, 2M particles per rank: replaying the step's segments as hipGraphs is 5 % SLOWER than
+  // launching its ~20 kernels one by one -- the host needs 45 us per step for them either way, the GPU 500 us;
+  // profiles/r02_slab_*.  Off unless asked for.)
+  L->use_graphs = false;
+  if (const char* e = std::getenv("DSL_SLAB_GRAPHS")) L->use_graphs = std::atoi(e) != 0;
   L->buf_floats = (size_t)(L->max_full + 1) * kRecordPci + (size_t)L->max_x * kRecordX;  // (13-float records once PCISPH runs)
   for (int k = 0; k < 2; ++k) {
     if (int rc = dev_alloc(h, &L->send[k], L->buf_floats)) return rc;
@@ -2030,6 +2049,73 @@ int dsl_slab_replan(dsl_handle* h) {
   return link_replan(h);
 }
 
+namespace {
+StepState step_state(const dsl_handle* h) {
+  return StepState{h->cur_pv,      h->cur_ids,    h->cur_f,          h->cur_pci,    h->grid_valid,   h->masks_valid,
+                   h->dens_fresh,  h->forces_uniform, h->press_zero, h->split_pending, h->pci_active};
+}
+void set_step_state(dsl_handle* h, const StepState& s) {
+  h->cur_pv = s.cur_pv;
+  h->cur_ids = s.cur_ids;
+  h->cur_f = s.cur_f;
+  h->cur_pci = s.cur_pci;
+  h->grid_valid = s.grid_valid;
+  h->masks_valid = s.masks_valid;
+  h->dens_fresh = s.dens_fresh;
+  h->forces_uniform = s.forces_uniform;
+  h->press_zero = s.press_zero;
+  h->split_pending = s.split_pending;
+}
+// run `body` (kernel launches on h->stream and host bookkeeping, nothing that synchronises): replayed from
+// its hipGraph when nothing it depends on has changed since the capture, captured (and launched) otherwise
+extern "C++" template <class F>
+int run_segment(dsl_handle* h, int which, F&& body) {
+  SlabLink& L = *h->link;
+  if (!L.use_graphs || h->timing != 0) return body();
+  const StepState now = step_state(h);
+  SegGraph& g = L.seg[which][now.cur_ids & 1];
+  if (g.exec && g.before == now && std::memcmp(&g.consts, &h->c, sizeof(DevConsts)) == 0 && g.cap_full == L.cap_full &&
+      g.cap_x == L.cap_x && g.shift_lo == L.shift_from_lo && g.shift_hi == L.shift_from_hi && g.width_full == L.width_full &&
+      g.width == L.width && g.split_width == h->split_width && g.stream == h->stream) {
+    HIP_TRY(h, hipGraphLaunch(g.exec, h->stream));
+    set_step_state(h, g.after);
+    return DSL_OK;
+  }
+  if (g.exec) {
+    (void)hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+  }
+  HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+  if (rc != DSL_OK || e != hipSuccess) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc != DSL_OK ? rc : fail(h, DSL_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  }
+  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ei != hipSuccess) {
+    g.exec = nullptr;
+    return fail(h, DSL_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+  }
+  g.before = now;
+  g.after = step_state(h);
+  g.consts = h->c;
+  g.cap_full = L.cap_full;
+  g.cap_x = L.cap_x;
+  g.shift_lo = L.shift_from_lo;
+  g.shift_hi = L.shift_from_hi;
+  g.width_full = L.width_full;
+  g.width = L.width;
+  g.split_width = h->split_width;
+  g.stream = h->stream;
+  L.captures++;
+  HIP_TRY(h, hipGraphLaunch(g.exec, h->stream));
+  return DSL_OK;
+}
+}  // namespace
+
 int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
   CHECK_HANDLE(h);
   if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_wcsph_step: call dsl_slab_attach first");
@@ -2038,28 +2124,59 @@ int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
   for (int s = 0; s < nsteps; ++s) {
     if (!L.ghosts_in)
       if (int rc = link_exchange(h)) return rc;  // first step: migrants + 2h ghosts from both neighbours
-    if (int rc = build_grid(h, false)) return rc;  // counting sort; drops the previous step's ghosts
-    if (int rc = density_pass(h)) return rc;        // owned + ghosts
     L.ghosts_in = false;
     if (alone || !L.overlap) {
-      if (int rc = force_integrate(h)) return rc;  // owned only; ghosts are marked for removal
-      if (int rc = link_exchange(h)) return rc;
+      // segment 0: counting sort (drops the previous step's ghosts), densities of owned + ghosts, forces and
+      // integration of the owned particles (ghosts are marked for removal), band pack
+      if (int rc = run_segment(h, 0, [&]() -> int {
+            if (int rc = build_grid(h, false)) return rc;
+            if (int rc = density_pass(h)) return rc;
+            if (int rc = force_integrate(h)) return rc;
+            if (alone) return DSL_OK;
+            return slab_pack_on(h, h->stream, L.width_full, L.width, false, L.lo >= 0 ? L.send[0] : nullptr,
+                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x);
+          }))
+        return rc;
+      if (!alone) {
+        if (int rc = link_post(h, h->stream)) return rc;
+        if (int rc = run_segment(h, 2, [&]() -> int { return link_append(h); })) return rc;
+        L.ghosts_in = true;
+      }
     } else {
       // band layers first; their pack and the RCCL transfer (side stream) run under the interior launch
-      if (!h->ev_band) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_band, hipEventDisableTiming));
-      if (int rc = force_integrate(h, 1)) return rc;
-      h->split_pending = true;
-      if (int rc = slab_pack_on(h, h->stream, L.width_full, h->split_width, true, L.lo >= 0 ? L.send[0] : nullptr,
-                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x))
+      const auto t0 = std::chrono::steady_clock::now();
+      if (int rc = run_segment(h, 0, [&]() -> int {
+            if (int rc = build_grid(h, false)) return rc;
+            if (int rc = density_pass(h)) return rc;
+            if (int rc = force_integrate(h, 1)) return rc;
+            h->split_pending = true;
+            return slab_pack_on(h, h->stream, L.width_full, h->split_width, true, L.lo >= 0 ? L.send[0] : nullptr,
+                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x);
+          }))
         return rc;
+      const auto t1 = std::chrono::steady_clock::now();
       HIP_TRY(h, hipEventRecord(L.ev_pack, h->stream));
       HIP_TRY(h, hipStreamWaitEvent(L.comm_stream, L.ev_pack, 0));
+      const auto t2 = std::chrono::steady_clock::now();
       if (int rc = link_post(h, L.comm_stream)) return rc;
+      const auto t3 = std::chrono::steady_clock::now();
       HIP_TRY(h, hipEventRecord(L.ev_xfer, L.comm_stream));
-      h->split_pending = false;
-      if (int rc = force_integrate(h, 2)) return rc;
+      const auto t4 = std::chrono::steady_clock::now();
+      if (int rc = run_segment(h, 1, [&]() -> int {
+            h->split_pending = false;
+            return force_integrate(h, 2);
+          }))
+        return rc;
+      const auto t5 = std::chrono::steady_clock::now();
       HIP_TRY(h, hipStreamWaitEvent(h->stream, L.ev_xfer, 0));
-      if (int rc = link_append(h)) return rc;
+      const auto t6 = std::chrono::steady_clock::now();
+      if (int rc = run_segment(h, 2, [&]() -> int { return link_append(h); })) return rc;
+      const auto t7 = std::chrono::steady_clock::now();
+      L.ghosts_in = true;
+      auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+      L.host_seg_s += sec(t0, t1) + sec(t4, t5) + sec(t6, t7);
+      L.host_post_s += sec(t2, t3);
+      L.host_sync_s += sec(t1, t2) + sec(t3, t4) + sec(t5, t6);
     }
     h->steps++;
     L.steps++;

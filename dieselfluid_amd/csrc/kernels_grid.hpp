@@ -137,17 +137,19 @@ __global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sum
 }
 
 // phase 3: exclusive scan inside each tile + tile offset; also tracks the fullest cell
-__global__ __launch_bounds__(kBlock) void k_scan_apply(const int* __restrict__ count,
+// (the histogram is left zeroed for the next build: saves that build a memset launch)
+__global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
                                                        const int* __restrict__ block_sums,
                                                        int* __restrict__ cell_start, DevStats* stats) {
   __shared__ int lds[kBlock / kWave];
-  const int4* src = reinterpret_cast<const int4*>(count + (size_t)blockIdx.x * kScanTile);
+  int4* src = reinterpret_cast<int4*>(count + (size_t)blockIdx.x * kScanTile);
   int4* dst = reinterpret_cast<int4*>(cell_start + (size_t)blockIdx.x * kScanTile);
   int carry = block_sums[blockIdx.x];
   int mx = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int4 v = src[k * kBlock + threadIdx.x];
+    src[k * kBlock + threadIdx.x] = make_int4(0, 0, 0, 0);
     mx = max(max(mx, max(v.x, v.y)), max(v.z, v.w));
     const int s = (v.x + v.y) + (v.z + v.w);
     int total;

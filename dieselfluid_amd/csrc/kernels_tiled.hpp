@@ -86,8 +86,15 @@ __device__ unsigned long long g_diag[32];
 __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                       int* __restrict__ tiles, int* __restrict__ n_tiles,
                                                       int* __restrict__ short_pass_tiles, int* __restrict__ n_live,
-                                                      int* __restrict__ desc_of) {
+                                                      int* __restrict__ desc_of, unsigned int* __restrict__ unordered,
+                                                      int unordered_words) {
   const int t = blockIdx.x * kBlock + threadIdx.x;
+  // the sort's "cells to order" bitmap (kernels_grid.hpp) has been consumed: clean for the next build
+  // (64 cells per tile = two words per tile thread; saves the build a memset launch)
+  if (unordered != nullptr) {
+    if (2 * t < unordered_words) unordered[2 * t] = 0u;
+    if (2 * t + 1 < unordered_words) unordered[2 * t + 1] = 0u;
+  }
   // slab mode: the sort has dropped the stale ghosts; the live count (kept on the device) is the
   // start of the pseudo cell behind the last one.  Nothing in this launch reads the count.
   if (t == 0 && n_live) *n_live = cell_start[c.ncell];
@@ -98,10 +105,16 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
     const int tx = t % tg.tnx, ty = (t / tg.tnx) % tg.tny, tz = t / (tg.tnx * tg.tny);
     const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
     const int xa = tx * kTB, xb = min(xa + kTB, nx);
-    for (int z = tz * kTB; z < min(tz * kTB + kTB, nz); ++z)
-      for (int y = ty * kTB; y < min(ty * kTB + kTB, ny); ++y) {
-        const int row = (z * ny + y) * nx;
-        cnt += cell_start[row + xb] - cell_start[row + xa];
+    // (fixed trip counts: all 32 loads of the tile's 16 rows are in flight together)
+#pragma unroll
+    for (int dz = 0; dz < kTB; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < kTB; ++dy) {
+        const int z = tz * kTB + dz, y = ty * kTB + dy;
+        if (z < nz && y < ny) {
+          const int row = (z * ny + y) * nx;
+          cnt += cell_start[row + xb] - cell_start[row + xa];
+        }
       }
     if (cnt > 0 && c.slab_axis >= 0) {
       const int a = c.slab_axis, ta = a == 0 ? tx : (a == 1 ? ty : tz);
@@ -484,6 +497,7 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
 // order with IEEE sqrt and divide, a handful of candidates instead of all of them.  One lane per target
 // always (sharing a target out would re-associate the sum).
 template <bool SHARE, bool EXACT = false>
+// (4 waves per SIMD = two workgroups per CU; held to 80 VGPRs for three, the FAST sweep spills and runs 7 % slower)
 __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                           const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                           const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
@@ -496,7 +510,9 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   static_assert(!(EXACT && SHARE), "the exact sum is sequential: one lane per target");
-  if (!EXACT && share_wanted(n_tiles) != SHARE) return;  // (n_tiles is the base of the tile-list counters here)
+  // (n_tiles is the base of the tile-list counters here; a slab always has half-empty ghost tiles: the host
+  // launches the pass-sharing instantiation alone)
+  if (!EXACT && c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
   auto load_rec = [&](int g, float* o) {
     o[0] = p.x[g];
     o[1] = p.y[g];

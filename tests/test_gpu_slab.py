@@ -248,11 +248,14 @@ def test_native_step_driver_matches_the_python_protocol():
         dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         res = {}
-        for kind in ("python", "native"):
+        # "native": the step's kernels are launched one by one (the default); "native_graphs": captured once
+        # and replayed as hipGraphs (DSL_SLAB_GRAPHS=1, read by dsl_slab_attach)
+        for kind in ("python", "native", "native_graphs"):
             for overlap in (False, True):
                 drv = PeriodicDriver.dambreak(64, math_mode=1, device=0, rank=1, world=4, overlap=overlap, native=False)
                 drv.comm_dev, drv.use_nccl = torch.device("cpu"), False
-                if kind == "native":
+                os.environ["DSL_SLAB_GRAPHS"] = "1" if kind == "native_graphs" else "0"
+                if kind != "python":
                     comm = Comm(1, 0, 0)
                     drv.attach_native(comm, 0, 0)
                     T = drv.hi - drv.lo
@@ -266,11 +269,13 @@ def test_native_step_driver_matches_the_python_protocol():
                 res[(kind, overlap)] = (ids[o], pos[o], vel[o])
                 drv.engine_core.close()
         for overlap in (False, True):
-            a, b = res[("python", overlap)], res[("native", overlap)]
-            assert np.array_equal(a[0], b[0]) and a[0].shape[0] > 60000
-            assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
-            assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+            for kind in ("native", "native_graphs"):
+                a, b = res[("python", overlap)], res[(kind, overlap)]
+                assert np.array_equal(a[0], b[0]) and a[0].shape[0] > 60000
+                assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+                assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     finally:
+        os.environ.pop("DSL_SLAB_GRAPHS", None)
         if created:
             dist.destroy_process_group()
 

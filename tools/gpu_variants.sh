@@ -6,7 +6,7 @@ mkdir -p $out
 for v in "$@"; do
   lib=dieselfluid_amd/lib/libdslsph_$v.so
   [ "$v" = base ] && lib=dieselfluid_amd/lib/libdslsph.so
-  DSL_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --developed-steps 0 > $out/var_$v.json 2> $out/var_$v.err || { echo "$v FAILED"; tail -3 $out/var_$v.err; exit 1; }
+  DSL_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --developed-steps 0 > $out/var_$v.json 2> $out/var_$v.err || { echo "$v FAILED"; tail -3 $out/var_$v.err; exit 1; }
   python - "$v" <<'PY'
 import json,sys
 v=sys.argv[1]
