@@ -497,15 +497,18 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
 // order with IEEE sqrt and divide, a handful of candidates instead of all of them.  One lane per target
 // always (sharing a target out would re-associate the sum).
 template <bool SHARE, bool EXACT = false>
-// (4 waves per SIMD = two workgroups per CU; held to 80 VGPRs for three, the FAST sweep spills and runs 7 % slower)
+// (4 waves per SIMD = two workgroups per CU.  Held to 80 VGPRs for three workgroups the FAST sweep still
+// compiles without spills and runs 7 % SLOWER, 0.845 against 0.794 ms at 16M: the kernel is bound by vector
+// instruction issue, not by latency, and more resident waves only add contention.)
 __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                           const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                           const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
                                                           float* __restrict__ rho, float* __restrict__ pterm,
                                                           unsigned int* __restrict__ nmask, int mstride) {
-  // Tiles are pipelined across the loop: while tile T is swept, the records of tile T+1 are on their
-  // way from HBM into registers (12 per lane) and the table of tile T+2 likewise (one dword per lane), so a
-  // tile's staging costs two barriers and some LDS writes instead of memory round trips.
+  // The NEXT tile's table (k_tile_desc) travels, one dword per lane, under the current tile's staging and is
+  // put into the other LDS copy behind it: a tile starts with ONE barrier and its table in place.
+  // (Carrying the next tile's records through the sweep as well -- 12 registers per lane -- bought nothing
+  // once the staging was down to three loads per lane: 0.794 ms with, 0.780 without, at 16M particles.)
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -513,33 +516,19 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   // (n_tiles is the base of the tile-list counters here; a slab always has half-empty ghost tiles: the host
   // launches the pass-sharing instantiation alone)
   if (!EXACT && c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
-  auto load_rec = [&](int g, float* o) {
-    o[0] = p.x[g];
-    o[1] = p.y[g];
-    o[2] = p.z[g];
-  };
-  auto load_quad = [&](int g, float4* o) {
-    o[0] = load4u(p.x + g);
-    o[1] = load4u(p.y + g);
-    o[2] = load4u(p.z + g);
-  };
   TileFeed feed(desc_of, *n_tiles);
-  int table_word = 0;   // a dword of the table of the tile after the one whose records are in flight
-  StageRegs<3> recs;    // records of the next tile to be swept
-  int di = 0, di_next = 0, di_after = 0;
-  if (!feed.pop(di)) return;
-  tile_meta_store(metas[0], tile_meta_request(desc, di));
-  __syncthreads();
-  stage_issue<3>(metas[0], load_quad, recs);
-  bool have_next = feed.pop(di_next);
-  if (have_next) table_word = tile_meta_request(desc, di_next);
-  for (int cur = 0;; cur ^= 1) {
+  int di = 0;
+  bool have = feed.pop(di);
+  if (have) tile_meta_store(metas[0], tile_meta_request(desc, di));
+  for (int cur = 0; have; cur ^= 1) {
     TileMeta& m = metas[cur];
-    TileMeta& mn = metas[cur ^ 1];
     DSL_STAMP(d0);
-    __syncthreads();  // the previous tile's sweep is over: its LDS records and the other table are free
+    __syncthreads();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
     DSL_STAMP(d1);
     DSL_STAMP_ADD(4, d0, d1);
+    have = feed.pop(di);
+    int table_word = 0;
+    if (have) table_word = tile_meta_request(desc, di);
     const bool ovf = m.overflow != 0;
     // tile centre in world coordinates
     const int tile = m.tile;
@@ -547,28 +536,33 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
     const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
     if (!ovf) {
-      stage_commit<3>(m, recs, load_rec, [&](int slot, const float* o, bool real) {
-        if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
-          A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
-          return;
-        }
-        float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
-        if (real) {
-          const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
-          v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-        }
-        A[slot] = v;
-      });
+      stage_rows<3>(
+          m,
+          [&](int g, float4* o) {
+            o[0] = load4u(p.x + g);
+            o[1] = load4u(p.y + g);
+            o[2] = load4u(p.z + g);
+          },
+          [&](int g, float* o) {
+            o[0] = p.x[g];
+            o[1] = p.y[g];
+            o[2] = p.z[g];
+          },
+          [&](int slot, const float* o, bool real) {
+            if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
+              A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
+              return;
+            }
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+            if (real) {
+              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+            }
+            A[slot] = v;
+          });
     }
-    if (have_next) tile_meta_store(mn, table_word);
+    if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
     __syncthreads();
-    bool have_after = false;
-    if (have_next) {
-      // every wave requests the next tile's records and its share of the table of the tile after it
-      stage_issue<3>(mn, load_quad, recs);
-      have_after = feed.pop(di_after);
-      if (have_after) table_word = tile_meta_request(desc, di_after);
-    }
     DSL_STAMP(d2);
     DSL_STAMP_ADD(5, d1, d2);
     const int ntarg = m.tprefix[kTB * kTB];
@@ -772,9 +766,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     });
     DSL_STAMP(d3);
     DSL_STAMP_ADD(6, d2, d3);
-    if (!have_next) break;
-    di_next = di_after;
-    have_next = have_after;
   }
 }
 
