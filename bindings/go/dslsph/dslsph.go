@@ -442,3 +442,123 @@ func (cp *ComputeGPU) Get() Descriptor        { return *cp.desc }
 func (cp *ComputeGPU) HasDeviceContext() bool { return cp.eng != nil && cp.eng.h != nil }
 func (cp *ComputeGPU) ValidState() bool       { return cp.HasDeviceContext() }
 func (cp *ComputeGPU) Log() string            { return cp.log }
+
+// ---- the rest of include/dslsph.h: one method per export, no logic -------------------------------------
+
+func Version() string { return C.GoString(C.dsl_version()) }
+
+func (e *Engine) GetParams() (C.dsl_params, error) {
+	var p C.dsl_params
+	err := e.ck(C.dsl_get_params(e.h, &p))
+	return p, err
+}
+func (e *Engine) ResetForces() error { return e.ck(C.dsl_reset_forces(e.h)) } // the state Update leaves (fluid.go:193)
+func (e *Engine) ForcePass() error   { return e.ck(C.dsl_force_pass(e.h)) }   // fused [G] [V] X U of the WCSPH step
+
+// SetStream: order the engine's launches on the caller's HIP stream (nil = the null stream); UseOwnStream undoes it.
+func (e *Engine) SetStream(hipStream unsafe.Pointer) error { return e.ck(C.dsl_set_stream(e.h, hipStream)) }
+func (e *Engine) UseOwnStream() error                      { return e.ck(C.dsl_use_own_stream(e.h)) }
+
+// Count: live particles (owned + ghosts) and owned particles of a slab engine; blocking.
+func (e *Engine) Count() (live, owned int, err error) {
+	var a, b C.int
+	err = e.ck(C.dsl_get_count(e.h, &a, &b))
+	return int(a), int(b), err
+}
+
+// Per-kernel timing (HIP events on the launch stream): mode 0 off, 1 every kernel, 2 the dominant kernels only.
+func (e *Engine) TimingEnable(mode int) error { return e.ck(C.dsl_timing_enable(e.h, C.int(mode))) }
+func (e *Engine) TimingReset() error          { return e.ck(C.dsl_timing_reset(e.h)) }
+func (e *Engine) Timing(kernelID int) (avgMs float64, launches int64, err error) {
+	var ms C.double
+	var n C.int64_t
+	err = e.ck(C.dsl_timing_get(e.h, C.int(kernelID), &ms, &n))
+	return float64(ms), int64(n), err
+}
+
+// Slot-order views (tests, debugging): a 3-component buffer without the un-sort, the slot -> particle id map,
+// the cell table of the current neighbour build.
+func (e *Engine) DownloadSorted(buffer C.int, out []float32) error {
+	return e.ck(C.dsl_download_sorted(e.h, buffer, (*C.float)(unsafe.Pointer(&out[0])), C.size_t(len(out))))
+}
+func (e *Engine) DownloadIDs(out []int32) error {
+	return e.ck(C.dsl_download_ids(e.h, (*C.int32_t)(unsafe.Pointer(&out[0])), C.size_t(len(out))))
+}
+func (e *Engine) DownloadCellStart(out []int32) error {
+	return e.ck(C.dsl_download_cell_start(e.h, (*C.int32_t)(unsafe.Pointer(&out[0])), C.size_t(len(out))))
+}
+
+// Slab pieces for a host that brings its own transport (INTEGRATION.md 7b); device pointers are the caller's.
+func SlabMessageFloats(capFull, capX int) int {
+	return int(C.dsl_slab_message_floats(C.int(capFull), C.int(capX)))
+}
+func (e *Engine) SlabMessageFloats(capFull, capX int) int {
+	return int(C.dsl_slab_message_floats_for(e.h, C.int(capFull), C.int(capX)))
+}
+func (e *Engine) SlabRecordFloats() int { return int(C.dsl_slab_record_floats(e.h)) }
+func (e *Engine) SlabSplit(width, margin float32) error {
+	return e.ck(C.dsl_slab_split(e.h, C.float(width), C.float(margin)))
+}
+func (e *Engine) ForcePassSplit(phase int) error { return e.ck(C.dsl_force_pass_split(e.h, C.int(phase))) }
+func (e *Engine) SlabPack(widthFull, width float32, devLo, devHi unsafe.Pointer, capFull, capX int) error {
+	return e.ck(C.dsl_slab_pack(e.h, C.float(widthFull), C.float(width), (*C.float)(devLo), (*C.float)(devHi), C.int(capFull), C.int(capX)))
+}
+func (e *Engine) SlabPackBand(widthFull float32, devLo, devHi unsafe.Pointer, capFull, capX int, stream unsafe.Pointer) error {
+	return e.ck(C.dsl_slab_pack_band(e.h, C.float(widthFull), (*C.float)(devLo), (*C.float)(devHi), C.int(capFull), C.int(capX), stream))
+}
+func (e *Engine) SlabAppend(devMsg unsafe.Pointer, capFull, capX int) error {
+	return e.ck(C.dsl_slab_append(e.h, (*C.float)(devMsg), C.int(capFull), C.int(capX)))
+}
+func (e *Engine) SlabAppend2(devMsgA, devMsgB unsafe.Pointer, capFull, capX int) error {
+	return e.ck(C.dsl_slab_append2(e.h, (*C.float)(devMsgA), (*C.float)(devMsgB), C.int(capFull), C.int(capX)))
+}
+
+// SlabStatus: [0] records that did not fit, [1] split margin outrun, [2], [3] band high-water marks.
+func (e *Engine) SlabStatus(resetHighWater bool) (st [4]int32, err error) {
+	r := C.int(0)
+	if resetHighWater {
+		r = 1
+	}
+	err = e.ck(C.dsl_slab_status(e.h, (*C.int32_t)(unsafe.Pointer(&st[0])), r))
+	return st, err
+}
+func (e *Engine) SlabOverflow() (highWater int, err error) {
+	var hw C.int
+	err = e.ck(C.dsl_slab_overflow(e.h, &hw))
+	return int(hw), err
+}
+func (e *Engine) SlabDetach() error   { return e.ck(C.dsl_slab_detach(e.h)) }
+func (e *Engine) SlabExchange() error { return e.ck(C.dsl_slab_exchange(e.h)) }
+
+// SlabImageShift: periodic images along the slab axis (a ring of ranks closes with -L / +L at its two ends).
+func (e *Engine) SlabImageShift(fromLo, fromHi float32) error {
+	return e.ck(C.dsl_slab_image_shift(e.h, C.float(fromLo), C.float(fromHi)))
+}
+
+// PCISPHErrorWord: copy the iteration's max density error out to / back in from a device word of the caller's
+// (the all-reduce between DSL_PCI_ITERATE and DSL_PCI_CHECK of a host-driven slab step).
+func (e *Engine) PCISPHErrorWord(devWord unsafe.Pointer, store bool) error {
+	s := C.int(0)
+	if store {
+		s = 1
+	}
+	return e.ck(C.dsl_pcisph_error_word(e.h, (*C.uint32_t)(devWord), s))
+}
+
+// NewCommAll: one process, several devices (ncclCommInitAll); NewEngines wraps it together with the handles.
+func NewCommAll(devices []int) ([]*Comm, error) {
+	n := len(devices)
+	devs := make([]C.int, n)
+	for k, d := range devices {
+		devs[k] = C.int(d)
+	}
+	cs := make([]*C.dsl_comm, n)
+	if rc := C.dsl_comm_create_all(C.int(n), &devs[0], &cs[0]); rc != 0 {
+		return nil, errors.New(C.GoString(C.dsl_comm_last_error()))
+	}
+	out := make([]*Comm, n)
+	for k := range cs {
+		out[k] = &Comm{c: cs[k]}
+	}
+	return out, nil
+}

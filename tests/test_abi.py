@@ -52,3 +52,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".go")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in src and "dsloracle" not in src and "dsl_oracle" not in src, f
+
+
+def test_go_binding_names_every_export():
+    """bindings/go/dslsph (the cgo stub a dieselfluid maintainer adds; not compilable here, no Go toolchain)
+    calls every function include/dslsph.h declares."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "dslsph.h")).read()
+    declared = set(re.findall(r"\b(dsl_[a-z_0-9]+)\s*\(", header))
+    go = ""
+    gdir = os.path.join(root, "bindings", "go", "dslsph")
+    for f in os.listdir(gdir):
+        if f.endswith(".go"):
+            go += open(os.path.join(gdir, f)).read()
+    bound = set(re.findall(r"C\.(dsl_[a-z_0-9]+)\b", go))
+    assert declared - bound == set(), sorted(declared - bound)
