@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int4 v = src[k * kBlock + threadIdx.x];
-    src[k * kBlock + threadIdx.x] = make_int4(0, 0, 0, 0);
+    // (most of the box is empty: only counts that are there are cleared)
+    if ((v.x | v.y | v.z | v.w) != 0) src[k * kBlock + threadIdx.x] = make_int4(0, 0, 0, 0);
     mx = max(max(mx, max(v.x, v.y)), max(v.z, v.w));
     const int s = (v.x + v.y) + (v.z + v.w);
     int total;

@@ -125,38 +125,50 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
       in_inner = owning && max(a0, c.split_cl) < min(a1, c.split_ch);
     }
   }
-  // tiles whose last pass is short (more than kTBlock targets, or at most half of it): the host
-  // picks the kernel instantiation that shares such passes out from this count
-  {
-    const unsigned long long sp = __ballot(cnt > kTBlock || (cnt > 0 && cnt <= kTBlock / 2));
-    if (sp != 0ull && lane == 0) atomicAdd(short_pass_tiles, __builtin_popcountll(sp));
+  // One atomic per BLOCK and list: same-address atomics serialise (one per wave was ~1500 of them on one
+  // counter at 16M particles, 22 of the kernel's 40 us).  The waves' counts meet in LDS, thread l asks for
+  // list l (l = kTileLists: the count of tiles whose last pass is short -- more than kTBlock targets, or at most
+  // half of it -- from which the kernels pick the instantiation that shares such passes out).
+  __shared__ int wave_count[kBlock / kWave][kTileLists + 1];
+  __shared__ int block_base[kTileLists + 1];
+  const int wid = threadIdx.x >> 6;
+  auto member = [&](int l) {
+    return l == 0 ? cnt > 0
+                  : (l == 1 ? in_band
+                            : (l == 2 ? in_inner
+                                      : (l == 3 ? ghosts : (l == 4 ? owning : (cnt > kTBlock || (cnt > 0 && cnt <= kTBlock / 2))))));
+  };
+  unsigned long long mask_of[kTileLists + 1];
+#pragma unroll
+  for (int l = 0; l <= kTileLists; ++l) {
+    mask_of[l] = __ballot(member(l));
+    if (lane == 0) wave_count[wid][l] = __builtin_popcountll(mask_of[l]);
   }
-  // one atomic per wave and list (same-address atomics serialise)
+  __syncthreads();
+  if (threadIdx.x <= kTileLists) {
+    int total = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) total += wave_count[w][threadIdx.x];
+    int* counter = threadIdx.x == kTileLists ? short_pass_tiles : n_tiles + threadIdx.x;
+    block_base[threadIdx.x] = total > 0 ? atomicAdd(counter, total) : 0;
+  }
+  __syncthreads();
   int pos0 = 0;
 #pragma unroll
   for (int l = 0; l < kTileLists; ++l) {
-    const bool in = l == 0 ? cnt > 0 : (l == 1 ? in_band : (l == 2 ? in_inner : (l == 3 ? ghosts : owning)));
-    const unsigned long long m = __ballot(in);
-    if (m == 0ull) continue;
-    const int leader = __builtin_ctzll(m);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(n_tiles + l, __builtin_popcountll(m));
-    base = __shfl(base, leader, kWave);
-    if (in) {
-      const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-      if (l == 0) pos0 = pos;
-      tiles[(size_t)l * tg.ntiles + pos] = t;
-      desc_of[(size_t)l * tg.ntiles + pos] = pos0;
-    }
+    if (!member(l)) continue;
+    int base = block_base[l];
+    for (int w = 0; w < wid; ++w) base += wave_count[w][l];
+    const int pos = base + __builtin_popcountll(mask_of[l] & ((1ull << lane) - 1ull));
+    if (l == 0) pos0 = pos;
+    tiles[(size_t)l * tg.ntiles + pos] = t;
+    desc_of[(size_t)l * tg.ntiles + pos] = pos0;
   }
 }
 
 // ---------------------------------------------------------------------------------
-// tile set-up shared by both kernels: row table, LDS offsets, target prefix
+// tile tables: row slot ranges, LDS offsets, per-cell offsets, target prefix (k_tile_desc)
 // ---------------------------------------------------------------------------------
-// The set-up in two halves, so that a kernel can have the NEXT tile's loads in flight while it
-// sweeps the current one: tile_setup_load issues the global loads of one staged row per lane
-// (lanes < kTRows) into registers, tile_setup_commit turns them into the row table (two barriers).
+// tile_setup_load: lane r < kTRows loads the cell table entries of staged row r of the tile
 struct TileSetupRegs {
   int s[kTH + 1];  // cell_start of the row's 6 cells and the end; all 0 for a row outside the grid
 };
@@ -181,68 +193,49 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
     }
   }
 }
-// commit, first half (lanes < kTRows): the row table as loaded
-__device__ __forceinline__ void tile_setup_raw(const TileSetupRegs& r, TileMeta& m) {
-  const int tid = threadIdx.x;
-  if (tid < kTRows) {
-    m.row_gs[tid] = r.s[0];
-    m.row_len[tid] = r.s[kTH] - r.s[0];
-#pragma unroll
-    for (int k = 0; k <= kTH; ++k) m.cellS[tid * (kTH + 1) + k] = r.s[k] - r.s[0];
-  }
-}
-// commit, second half (wave 0, behind a barrier): LDS offsets of the rows and the target prefix
-__device__ __forceinline__ void tile_setup_scan(TileMeta& m) {
-  const int tid = threadIdx.x;
-  if (tid < kWave) {  // wave 0: exclusive prefix of (len + pad) over the 36 rows
-    const int v = tid < kTRows ? m.row_len[tid] + kTPad : 0;
-    const int inc = wave_inclusive_scan(v);
-    if (tid < kTRows) m.row_lds[tid] = inc - v;
-    if (tid == kTRows - 1) {
-      m.row_lds[kTRows] = inc;
-      m.overflow = inc > kTCap ? 1 : 0;
-    }
-    // targets: interior rows (ry,rz in 1..4), interior cells 1..4
-    int tv = 0;
-    if (tid < kTB * kTB) {
-      const int rr = (tid / kTB + 1) * kTH + (tid % kTB + 1);
-      tv = m.cellS[rr * (kTH + 1) + kTB + 1] - m.cellS[rr * (kTH + 1) + 1];
-    }
-    const int tinc = wave_inclusive_scan(tv);
-    if (tid < kTB * kTB) m.tprefix[tid] = tinc - tv;
-    if (tid == kTB * kTB - 1) m.tprefix[kTB * kTB] = tinc;
-  }
-}
-__device__ __forceinline__ void tile_setup_commit(const TileSetupRegs& r, TileMeta& m) {
-  tile_setup_raw(r, m);
-  __syncthreads();
-  tile_setup_scan(m);
-  __syncthreads();
-}
-__device__ __forceinline__ void tile_setup(const DevConsts& c, const TileGrid& tg, int tile,
-                                           const int* __restrict__ cell_start, TileMeta& m) {
-  TileSetupRegs r;
-  tile_setup_load(c, tg, tile, cell_start, r);
-  tile_setup_commit(r, m);
-}
-
 // One wave per non-empty tile (tile list 0): the tile's table, written where the sweeping kernels
-// pick it up.  ~31k tiles x 1.5 KB at 16M particles.
+// pick it up.  ~31k tiles x 1.5 KB at 16M particles.  Lane r holds staged row r; the two prefix sums
+// run over the lanes (no LDS, no barrier), every lane writes its own row's entries.
 __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                      const int* __restrict__ tiles, const int* __restrict__ n_tiles,
                                                      int* __restrict__ desc) {
-  __shared__ TileMeta m;
   const int n = *n_tiles;
-  for (int item = blockIdx.x; item < n; item += gridDim.x) {
-    const int tile = tiles[item];
-    tile_setup(c, tg, tile, cell_start, m);
-    if (threadIdx.x == 0) m.tile = tile;
-    __syncthreads();
-    const int* src = reinterpret_cast<const int*>(&m);
-    int* out = desc + (size_t)item * kMetaInts;
+  const int lane = threadIdx.x;
+  const int ry = lane % kTH, rz = lane / kTH;
+  const bool row = lane < kTRows;
+  const bool interior = row && ry >= 1 && ry <= kTB && rz >= 1 && rz <= kTB;
+  // (two tiles per trip: the second one's loads travel under the first one's sums)
+  auto table = [&](int item, int tile, const TileSetupRegs& r) {
+    TileMeta* out = reinterpret_cast<TileMeta*>(desc + (size_t)item * kMetaInts);
+    const int len = r.s[kTH] - r.s[0];
+    const int v = row ? len + kTPad : 0;
+    const int inc = wave_inclusive_scan(v);  // LDS offsets: rows are kTPad apart
+    const int tv = interior ? r.s[kTB + 1] - r.s[1] : 0;
+    const int tinc = wave_inclusive_scan(tv);  // targets: interior rows, interior cells
+    if (row) {
+      out->row_gs[lane] = r.s[0];
+      out->row_len[lane] = len;
+      out->row_lds[lane] = inc - v;
 #pragma unroll
-    for (int k = 0; k < kMetaInts / kWave; ++k) out[k * kWave + threadIdx.x] = src[k * kWave + threadIdx.x];
-    __syncthreads();
+      for (int k = 0; k <= kTH; ++k) out->cellS[lane * (kTH + 1) + k] = r.s[k] - r.s[0];
+      if (interior) out->tprefix[(rz - 1) * kTB + (ry - 1)] = tinc - tv;
+      if (lane == kTRows - 1) {  // (the last interior row is lane 28: this lane's inclusive sums are the totals)
+        out->row_lds[kTRows] = inc;
+        out->overflow = inc > kTCap ? 1 : 0;
+        out->tprefix[kTB * kTB] = tinc;
+        out->tile = tile;
+      }
+    }
+  };
+  for (int item = blockIdx.x; item < n; item += 2 * gridDim.x) {
+    const int item2 = item + gridDim.x;
+    const bool two = item2 < n;
+    const int tile = tiles[item], tile2 = two ? tiles[item2] : 0;
+    TileSetupRegs r, r2;
+    tile_setup_load(c, tg, tile, cell_start, r);
+    if (two) tile_setup_load(c, tg, tile2, cell_start, r2);
+    table(item, tile, r);
+    if (two) table(item2, tile2, r2);
   }
 }
 
