@@ -513,7 +513,8 @@ int force_integrate(dsl_handle* h, int part = 0) {
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->tile_desc, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
-                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, ((XX) || (SS)) ? nullptr : h->n_tiles, bnd_of(h))
+                     po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, ((XX) || (SS)) ? nullptr : h->n_tiles, bnd_of(h), \
+                     Soa3{nullptr, nullptr, nullptr})
   // (the XSPH / cohesion variant and the slab variant -- a slab always has half-empty ghost tiles -- exist
   // as the pass-sharing instantiation only; of the other two the device picks: kernels_tiled.hpp, share_wanted)
 #define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                        \
@@ -551,7 +552,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
 #define DSL_LAUNCH_FX(GG, VV, XX)                                                                                  \
   hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, false, false, true>), g, b, 0, h->stream, c, \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->tile_desc, h->cell_start, p, v, h->rho, h->pterm, f, uni, po, vo, \
-                     h->dstats, h->nmask, h->cap, nullptr, bnd_of(h))
+                     h->dstats, h->nmask, h->cap, nullptr, bnd_of(h), Soa3{nullptr, nullptr, nullptr})
       if (XS) {
         if (G && V) DSL_LAUNCH_FX(true, true, true);
         else if (G) DSL_LAUNCH_FX(true, false, true);
@@ -1417,21 +1418,17 @@ int pci_begin_step(dsl_handle* h) {
     Soa3 G{h->gterm[0], h->gterm[1], h->gterm[2]};
     Soa3 none{nullptr, nullptr, nullptr};
     Soa3 xs{h->xsph[0], h->xsph[1], h->xsph[2]};
-    int rc = timed(h, DSL_K_VISCOUS, [&] {         // ViscousAll  :45 (+ cohesion, XSPH sums)
+    // ViscousAll :45 (+ cohesion, XSPH sums) and GradientPressureForce's term, which is the same in every
+    // correction iteration: one sweep over the masks for both
+    int rc = timed(h, DSL_K_VISCOUS, [&] {
       if (XS)
-        hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce, true>), dim3(persistent_grid(h, 2)),
+        hipLaunchKernelGGL((k_force_integrate_tiled<true, true, kOutPci, true>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
+                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h), G);
       else
-        hipLaunchKernelGGL((k_force_integrate_tiled<false, true, kOutAddForce>), dim3(persistent_grid(h, 2)),
+        hipLaunchKernelGGL((k_force_integrate_tiled<true, true, kOutPci>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
-    });
-    if (rc) return rc;
-    rc = timed(h, DSL_K_GRADIENT, [&] {            // GradientPressureForce's term, once
-      hipLaunchKernelGGL((k_force_integrate_tiled<true, false, kOutStore>), dim3(persistent_grid(h, 2)),
-                         dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
-                         h->pterm, cF, 0, G, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h));
+                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h), G);
     });
     if (rc) return rc;
   } else {
@@ -1450,33 +1447,28 @@ int pci_iterate(dsl_handle* h) {
   Soa3 F = mfrc(h);
   CSoa3 cF{F.x, F.y, F.z};
   Soa3 pp = mpcip(h), pvv = mpciv(h);
+  const bool tiled = pci_tiled(h);
+  if (tiled) {  // predict, DensityF + pressure, F += cached gradient term: one launch (kernels_tiled.hpp)
+    CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
+    return timed(h, DSL_K_PCI_DENSITY, [&] {
+      hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                         h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), p, pp, pvv, cG, F, h->press,
+                         h->dstats);
+    });
+  }
   int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
     hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, bnd_of(h), cF, pp, pvv, h->dstats);
   });
   if (rc) return rc;
   CSoa3 cpp{pp.x, pp.y, pp.z};
-  const bool tiled = pci_tiled(h);
   rc = timed(h, DSL_K_PCI_DENSITY, [&] {
-    if (tiled)
-      hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                         h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), p, cpp, h->press, h->dstats);
-    else
-      by_math(h, [&](auto fast) {
-        hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), bnd_of(h), p, cpp,
-                           h->press, h->dstats);
-      });
+    by_math(h, [&](auto fast) {
+      hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), bnd_of(h), p, cpp,
+                         h->press, h->dstats);
+    });
   });
   if (rc) return rc;
-  if (tiled) {
-    CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
-    rc = timed(h, DSL_K_GRADIENT, [&] {
-      hipLaunchKernelGGL(k_pci_add_gradient, g, b, 0, h->stream, c, cG, F, h->dstats);
-    });
-    if (rc) return rc;
-  } else if ((rc = gradient_pass(h, 1))) {      // GradientPressureForce :93
-    return rc;
-  }
-  return DSL_OK;
+  return gradient_pass(h, 1);  // GradientPressureForce :93
 }
 
 int pci_check(dsl_handle* h) {                   // :95-98

@@ -769,7 +769,10 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
 //   kOutIntegrate  fused WCSPH step: F = reset/forces [+G] [+V] + ext, then Update (pout/vout)
 //   kOutAddForce   the reference's stand-alone passes: forces[pout] += G-term (+ V-term)
 //   kOutStore      pout = G-term (PCISPH: the gradient term is the same in every iteration)
-constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2;
+//   kOutPci        both of those in ONE sweep (PCISPH step set-up): forces[pout] += V-term (+ cohesion), gout =
+//                  G-term; each sum is formed exactly as in its own pass (the two passes cost 0.245 + 0.204 ms at
+//                  4M particles, mostly per-tile and per-run work they share)
+constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2, kOutPci = 3;
 
 // WANT_XS adds the build-defined XSPH and cohesion sums (BASELINE configs[4]) to the same sweep;
 // with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int* __restrict__ ghost_desc_of, const int* __restrict__ n_ghost_tiles, const int* __restrict__ desc,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
-    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd) {
+    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd, Soa3 gout) {
   static_assert(!(EXACT && SHARE), "the exact sums are sequential: one lane per target");
   if (share_stats != nullptr && share_wanted(share_stats) != SHARE) return;
   __shared__ TileMeta metas[2];
@@ -905,6 +908,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       }
       float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
       float xsx = 0.f, xsy = 0.f, xsz = 0.f;  // XSPH sum / correction
+      float gfx = 0.f, gfy = 0.f, gfz = 0.f;  // kOutPci: the gradient term, kept apart from the force
       bool owned = false;
       float pti_staged = 0.f;
       if (live) {
@@ -1285,9 +1289,15 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             const float dm = rho[g] * c.mass;
             const float tx = gx * dm, ty = gy * dm, tz = gz * dm;
             const float sx = tx * c.pressure_sign, sy = ty * c.pressure_sign, sz = tz * c.pressure_sign;
-            fx += sx;
-            fy += sy;
-            fz += sz;
+            if constexpr (OUT == kOutPci) {
+              gfx = 0.0f + sx;
+              gfy = 0.0f + sy;
+              gfz = 0.0f + sz;
+            } else {
+              fx += sx;
+              fy += sy;
+              fz += sz;
+            }
           }
           if constexpr (WANT_V) {
             const float tx = lx_ * c.mu, ty = ly_ * c.mu, tz = lz_ * c.mu;
@@ -1307,9 +1317,15 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
         } else {
         if constexpr (WANT_G) {
           const float dm = rho[g] * c.mass * c.pressure_sign;
-          fx = __builtin_fmaf(gx, dm, fx);
-          fy = __builtin_fmaf(gy, dm, fy);
-          fz = __builtin_fmaf(gz, dm, fz);
+          if constexpr (OUT == kOutPci) {
+            gfx = __builtin_fmaf(gx, dm, 0.0f);
+            gfy = __builtin_fmaf(gy, dm, 0.0f);
+            gfz = __builtin_fmaf(gz, dm, 0.0f);
+          } else {
+            fx = __builtin_fmaf(gx, dm, fx);
+            fy = __builtin_fmaf(gy, dm, fy);
+            fz = __builtin_fmaf(gz, dm, fz);
+          }
         }
         if constexpr (WANT_V) {
           fx = __builtin_fmaf(lx_, c.mu, fx);
@@ -1336,7 +1352,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       if constexpr (SHARED) {
         if (sub != 0) return;  // the group's first lane finishes the target
       }
-      if constexpr (OUT == kOutAddForce) {
+      if constexpr (OUT == kOutAddForce || OUT == kOutPci) {
         pout.x[g] += fx;
         pout.y[g] += fy;
         pout.z[g] += fz;
@@ -1344,6 +1360,11 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
           vout.x[g] = xsx;
           vout.y[g] = xsy;
           vout.z[g] = xsz;
+        }
+        if constexpr (OUT == kOutPci) {
+          gout.x[g] = gfx;
+          gout.y[g] = gfy;
+          gout.z[g] = gfz;
         }
         return;
       }
@@ -1387,16 +1408,20 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
 }
 
 // ---------------------------------------------------------------------------------
-// DF (tiled): SPHField.DensityF at the PREDICTED positions (sph_field.go:137-152) +
-// pressure accumulate + max error (pcisph_darwin.go:76-92).  Candidates are the current
-// positions of the staged tile; a target whose predicted position has left the tile interior
-// (the reference never re-synchronises the predictor, so it may) falls back to the
-// global-memory sweep.
+// One PCISPH correction iteration up to its convergence check (pcisph_darwin.go:52-94), per target:
+// predict (_vel += F/m dt, _pos += _vel dt, :57-73; the operations of k_pci_predict), DF (tiled):
+// SPHField.DensityF at the PREDICTED position (sph_field.go:137-152) + pressure accumulate + max error
+// (:76-92), then GradientPressureForce's cached term F += G (:93).  Every piece reads only the target's own
+// state and its neighbours' CURRENT positions, so the three passes of an iteration are one launch (they used to
+// be three: 0.042 + 0.192 + 0.026 ms at 4M particles).  Candidates are the current positions of the staged
+// tile; a target whose predicted position has left the tile interior (the reference never re-synchronises
+// the predictor, so it may) falls back to the global-memory sweep.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                               const int* __restrict__ n_tiles, const int* __restrict__ desc,
-                                                              const int* __restrict__ cell_start, Bnd bnd, CSoa3 p, CSoa3 pp,
-                                                              float* __restrict__ press, DevStats* stats) {
+                                                              const int* __restrict__ cell_start, Bnd bnd, CSoa3 p, Soa3 pp,
+                                                              Soa3 pv, CSoa3 gterm, Soa3 frc, float* __restrict__ press,
+                                                              DevStats* stats) {
   if (stats->pci_done) return;
   __shared__ TileMeta m;
   __shared__ float4 A[kTCap];
@@ -1446,8 +1471,24 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       const int g = m.row_gs[srow] + off;
       // slab mode: a ghost's predicted density is meaningless (half a neighbourhood, no predictor
       // state) and must not decide the iteration's error
+      // (a ghost is not predicted either: its predictor state travels with the particle from its owner)
       if (!slab_owned(c, p.x[g], p.y[g], p.z[g]) || bnd.is(g)) continue;
-      const float qx = pp.x[g], qy = pp.y[g], qz = pp.z[g];
+      const float fx = frc.x[g], fy = frc.y[g], fz = frc.z[g];
+      const float gx = gterm.x[g], gy = gterm.y[g], gz = gterm.z[g];
+      const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
+      const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
+      const float tvx = pv.x[g] + dvx, tvy = pv.y[g] + dvy, tvz = pv.z[g] + dvz;
+      const float dpx = tvx * c.dt, dpy = tvy * c.dt, dpz = tvz * c.dt;
+      const float qx = pp.x[g] + dpx, qy = pp.y[g] + dpy, qz = pp.z[g] + dpz;
+      pp.x[g] = qx;
+      pp.y[g] = qy;
+      pp.z[g] = qz;
+      pv.x[g] = tvx;
+      pv.y[g] = tvy;
+      pv.z[g] = tvz;
+      frc.x[g] = fx + gx;
+      frc.y[g] = fy + gy;
+      frc.z[g] = fz + gz;
       // tile-local cell of the predicted position; the LDS image covers it and its 26
       // neighbours only while it stays inside the tile interior (1..4 per axis)
       const int lx = cell_coord(qx, c.gmin[0], c.inv_cell, c.dims[0]) - (tx * kTB - 1);
@@ -1507,16 +1548,6 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
     }
   }
   wave_atomic_max(&stats->pci_cur_err_bits, ebits);
-}
-
-// F += cached gradient term (one per PCISPH correction iteration, pcisph_darwin.go:93)
-__global__ __launch_bounds__(kBlock) void k_pci_add_gradient(DevConsts c, CSoa3 gterm, Soa3 f, const DevStats* stats) {
-  if (stats->pci_done) return;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
-  f.x[i] += gterm.x[i];
-  f.y[i] += gterm.y[i];
-  f.z[i] += gterm.z[i];
 }
 
 }  // namespace dsl
