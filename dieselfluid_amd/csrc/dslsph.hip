@@ -214,8 +214,9 @@ inline int launch_n(const dsl_handle* h) { return h->c.n_ptr ? h->cap : h->n; }
 
 template <class T>
 int dev_alloc(dsl_handle* h, T** p, size_t count) {
-  // (16 bytes of padding: the staging quads of the tiled kernels read up to three elements past a row)
-  hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 16);
+  // (64 bytes of padding: the staging quads of the tiled kernels read up to three elements past a row, the ordered
+  // scatter up to seven keys past a cell)
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 64);
   if (e != hipSuccess) return fail(h, DSL_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
   return DSL_OK;
 }
