@@ -1094,11 +1094,13 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // `first_word`: the run's first mask word, loaded by the caller one run ahead so that its
             // global-memory latency passes under the previous run's walk
             // (the run's LDS record range [j, je) likewise comes from the caller)
-            auto run_bounds = [&](int ri, int& j, int& je) {
-              const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
+            auto run_bounds_of_row = [&](int rr, int& j, int& je) {
               const int rb = m.row_lds[rr];
               j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
               je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            };
+            auto run_bounds = [&](int ri, int& j, int& je) {
+              run_bounds_of_row(srow + (ri / 3 - 1) * kTH + (ri % 3 - 1), j, je);
             };
             // `second_word`: the mask of candidates 32-63, requested by the caller together with the first
             // word.  (Once the lattice has melted ~10 % of the runs are that long, so in nearly every run
@@ -1168,28 +1170,35 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               const int sy = (fy - floorf(fy)) >= 0.5f ? 1 : -1, sz = (fz - floorf(fz)) >= 0.5f ? 1 : -1;
               // (the centre run, the same for every mirroring, comes first: its mask word can be
               // requested before the position is known, and its walk, the longest, covers the next word's latency)
+              // (the loop over the 9 steps is unrolled: a step's (dz, dy) before mirroring are constants, the run
+              // index and its staged row one or two operations each instead of a division by 3 per lane)
               auto run_of = [&](int s) {
                 if constexpr (EXACT) return s;  // z, y order: the reference's
                 const int ms = s == 0 ? 4 : (s <= 4 ? s - 1 : s);
                 return ((ms / 3 - 1) * sz + 1) * 3 + ((ms % 3 - 1) * sy + 1);
               };
+              auto row_of = [&](int s) {
+                if constexpr (EXACT) return srow + (s / 3 - 1) * kTH + (s % 3 - 1);
+                const int ms = s == 0 ? 4 : (s <= 4 ? s - 1 : s);
+                return srow + (ms / 3 - 1) * sz * kTH + (ms % 3 - 1) * sy;
+              };
               int rn = run_of(0);
               unsigned int ahead =
                   first_pass ? pre_word : (nmask != nullptr ? nmask[(size_t)rn * mstride + g] : 0u);  // (not behind runs_masked)
               int jn, jen;
-              run_bounds(rn, jn, jen);
+              run_bounds_of_row(row_of(0), jn, jen);
               auto second_of = [&](int ri, int j, int je) {
                 return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? nmask[(size_t)(kMaskHigh + ri) * mstride + g] : 0u;
               };
               unsigned int ahead2 = second_of(rn, jn, jen);
-#pragma unroll 1
+#pragma unroll
               for (int s = 0; s < 9; ++s) {
                 const unsigned int word = ahead, word2 = ahead2;
                 const int j = jn, je = jen, ri = rn;
                 if (s < 8) {
                   rn = run_of(s + 1);
                   if (runs_masked != 0u) ahead = nmask[(size_t)rn * mstride + g];
-                  run_bounds(rn, jn, jen);
+                  run_bounds_of_row(row_of(s + 1), jn, jen);
                   ahead2 = second_of(rn, jn, jen);
                 }
                 walk_run(ri, j, je, word, word2);
