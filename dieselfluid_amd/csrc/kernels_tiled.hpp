@@ -1106,59 +1106,62 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // word.  (Once the lattice has melted ~10 % of the runs are that long, so in nearly every run
             // of a wave SOME lane needs its second word: fetched here, inside the walk, that was one exposed
             // HBM latency per run and wave.)
-            auto walk_run = [&](int ri, int j, const int je, unsigned int first_word, unsigned int second_word) {
-              const bool has_mask = (runs_masked >> ri) & 1u;
-              int word = ri;
-              do {
-                const int clen = min(je - j, 32);
-                unsigned int mm = clen >= 32 ? ~0u : ((1u << clen) - 1u);
-                int top = j + clen - 1;
-                if (has_mask) {  // (then the run has at most 64 candidates: two words)
-                  mm = word == ri ? first_word : second_word;
-                  top = j + ((clen + 3) & ~3) - 1;
-                  word = kMaskHigh + ri;
-                }
+            // the in-range bits of one mask word (or of a chunk of up to 32 unmasked candidates): bit b <-> record top - b
+            auto walk_bits = [&](unsigned int mm, const int top) {
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: measures the per-tile fixed cost (set-up + staging + epilogue)
-                mm = 0u;
+              mm = 0u;
 #endif
-                // Every lane stays in the walk until the last bit of the wave is done: a lane that has
-                // run out of bits works on a far-away pad record, whose terms are all exactly zero.  That
-                // makes the loop wave-uniform (no exec bookkeeping) and lets it be software-pipelined:
-                // kPairsPerTrip pairs per trip, the next trip's LDS reads issued before the current
-                // trip's arithmetic.  (The old loop waited out one LDS latency plus one dependent chain
-                // of ~20 VALU instructions per pair: 5.9 clocks per instruction at 4 waves per SIMD.)
-                auto take = [&]() {
-                  const bool has = mm != 0u;
-                  if constexpr (EXACT) {  // highest bit = earliest candidate first: the reference's order
-                    const int b = 31 - __builtin_clz(mm | 1u);
-                    const int idx = has ? top - b : pad_rec;
-                    mm = has ? (mm & ~(1u << b)) : 0u;
-                    return idx;
-                  } else {
-                    const int idx = has ? top - __builtin_ctz(mm) : pad_rec;
-                    mm &= mm - 1u;
-                    return idx;
-                  }
-                };
-                if (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
-                  // (one exit, both pairs of a trip unconditional: with an exit between a fetch and its
-                  // use the compiler sinks the LDS reads below the branch and the prefetch is gone; the
-                  // price is one all-pad pair when the wave's longest lane has an odd number of bits)
-                  PairRec p = fetch(take());
-                  bool more;
-                  // (two pairs per trip cost one all-pad pair whenever the wave's longest lane has an odd number
-                  // of bits, ~0.5 per run; one pair per trip avoids that and pays it back in register copies --
-                  // 35 instead of 31 VALU instructions per pair: measured equal, 0.940 vs 0.937 ms)
-                  do {
-                    const PairRec q = fetch(take());
-                    accum(p);
-                    more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
-                    p = fetch(take());
-                    accum(q);
-                  } while (more);
+              // Every lane stays in the walk until the last bit of the wave is done: a lane that has
+              // run out of bits works on a far-away pad record, whose terms are all exactly zero.  That
+              // makes the loop wave-uniform (no exec bookkeeping) and lets it be software-pipelined:
+              // kPairsPerTrip pairs per trip, the next trip's LDS reads issued before the current
+              // trip's arithmetic.  (The old loop waited out one LDS latency plus one dependent chain
+              // of ~20 VALU instructions per pair: 5.9 clocks per instruction at 4 waves per SIMD.)
+              auto take = [&]() {
+                const bool has = mm != 0u;
+                if constexpr (EXACT) {  // highest bit = earliest candidate first: the reference's order
+                  const int b = 31 - __builtin_clz(mm | 1u);
+                  const int idx = has ? top - b : pad_rec;
+                  mm = has ? (mm & ~(1u << b)) : 0u;
+                  return idx;
+                } else {
+                  const int idx = has ? top - __builtin_ctz(mm) : pad_rec;
+                  mm &= mm - 1u;
+                  return idx;
                 }
-                j += 32;
-              } while (j < je);
+              };
+              if (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
+                // (one exit, both pairs of a trip unconditional: with an exit between a fetch and its
+                // use the compiler sinks the LDS reads below the branch and the prefetch is gone; the
+                // price is one all-pad pair when the wave's longest lane has an odd number of bits)
+                PairRec p = fetch(take());
+                bool more;
+                // (two pairs per trip cost one all-pad pair whenever the wave's longest lane has an odd number
+                // of bits, ~0.5 per run; one pair per trip avoids that and pays it back in register copies --
+                // 35 instead of 31 VALU instructions per pair: measured equal, 0.940 vs 0.937 ms)
+                do {
+                  const PairRec q = fetch(take());
+                  accum(p);
+                  more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
+                  p = fetch(take());
+                  accum(q);
+                } while (more);
+              }
+            };
+            // A run: its first 32 candidates in straight-line code -- on a lattice, and wherever no lane of the
+            // wave has a run longer than that, this is all there is -- then, lane by lane, the chunks behind them
+            // (the second mask word, or chunks of 32 with every bit set for a run without a mask).
+            auto walk_run = [&](int ri, const int j, const int je, unsigned int first_word, unsigned int second_word) {
+              const bool has_mask = (runs_masked >> ri) & 1u;
+              auto chunk = [&](int from, unsigned int word) {
+                const int clen = min(je - from, 32);
+                const unsigned int all = clen >= 32 ? ~0u : ((1u << clen) - 1u);
+                // (a mask's bit order counts from the run length rounded up to the density sweep's unroll of 4)
+                walk_bits(has_mask ? word : all, from + (has_mask ? ((clen + 3) & ~3) : clen) - 1);
+              };
+              chunk(j, first_word);
+              if (__builtin_amdgcn_ballot_w64(je - j > 32) != 0ull)
+                for (int from = j + 32; from < je; from += 32) chunk(from, second_word);
             };
             if constexpr (!SHARED) {
               // The wave spends, on every run, as many iterations as its busiest lane has neighbours
