@@ -1153,11 +1153,19 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // (the second mask word, or chunks of 32 with every bit set for a run without a mask).
             auto walk_run = [&](int ri, const int j, const int je, unsigned int first_word, unsigned int second_word) {
               const bool has_mask = (runs_masked >> ri) & 1u;
+              // (a run without a mask -- longer than 64 candidates, or no masks at all -- is rare: the selects
+              // between a mask word and "every bit set" are only compiled into the path some lane needs them on)
+              // (not in the XSPH / cohesion instantiations: they are at the register limit, a second copy of the walk spills)
+              const bool all_masked = !WANT_XS && __builtin_amdgcn_ballot_w64(!has_mask) == 0ull;
               auto chunk = [&](int from, unsigned int word) {
                 const int clen = min(je - from, 32);
-                const unsigned int all = clen >= 32 ? ~0u : ((1u << clen) - 1u);
                 // (a mask's bit order counts from the run length rounded up to the density sweep's unroll of 4)
-                walk_bits(has_mask ? word : all, from + (has_mask ? ((clen + 3) & ~3) : clen) - 1);
+                if (all_masked) {
+                  walk_bits(word, from + ((clen + 3) & ~3) - 1);
+                } else {
+                  const unsigned int all = clen >= 32 ? ~0u : ((1u << clen) - 1u);
+                  walk_bits(has_mask ? word : all, from + (has_mask ? ((clen + 3) & ~3) : clen) - 1);
+                }
               };
               chunk(j, first_word);
               if (__builtin_amdgcn_ballot_w64(je - j > 32) != 0ull)
@@ -1185,24 +1193,32 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 const int ms = s == 0 ? 4 : (s <= 4 ? s - 1 : s);
                 return srow + (ms / 3 - 1) * sz * kTH + (ms % 3 - 1) * sy;
               };
+              // the step's mask word: plane run_of(s) of the particle's column.  The plane offset is the centre
+              // run's plus or minus the (64-bit) strides of one run in z and in y, mirrored like the run itself:
+              // one or two additions per step instead of a 64-bit multiply per lane
+              const unsigned int* mcol = nmask != nullptr ? nmask + g : nullptr;
+              const long long my = (long long)(EXACT ? 1 : sy) * mstride, mz = (long long)(EXACT ? 3 : 3 * sz) * mstride;
+              auto word_of = [&](int s, int plane0) -> const unsigned int* {
+                const int ms = EXACT ? s : (s == 0 ? 4 : (s <= 4 ? s - 1 : s));
+                return mcol + (long long)(plane0 + 4) * mstride + (ms / 3 - 1) * mz + (ms % 3 - 1) * my;
+              };
               int rn = run_of(0);
-              unsigned int ahead =
-                  first_pass ? pre_word : (nmask != nullptr ? nmask[(size_t)rn * mstride + g] : 0u);  // (not behind runs_masked)
+              unsigned int ahead = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);  // (not behind runs_masked)
               int jn, jen;
               run_bounds_of_row(row_of(0), jn, jen);
-              auto second_of = [&](int ri, int j, int je) {
-                return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? nmask[(size_t)(kMaskHigh + ri) * mstride + g] : 0u;
+              auto second_of = [&](int s, int ri, int j, int je) {
+                return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? *word_of(s, kMaskHigh) : 0u;
               };
-              unsigned int ahead2 = second_of(rn, jn, jen);
+              unsigned int ahead2 = second_of(0, rn, jn, jen);
 #pragma unroll
               for (int s = 0; s < 9; ++s) {
                 const unsigned int word = ahead, word2 = ahead2;
                 const int j = jn, je = jen, ri = rn;
                 if (s < 8) {
                   rn = run_of(s + 1);
-                  if (runs_masked != 0u) ahead = nmask[(size_t)rn * mstride + g];
+                  if (runs_masked != 0u) ahead = *word_of(s + 1, 0);
                   run_bounds_of_row(row_of(s + 1), jn, jen);
-                  ahead2 = second_of(rn, jn, jen);
+                  ahead2 = second_of(s + 1, rn, jn, jen);
                 }
                 walk_run(ri, j, je, word, word2);
               }
