@@ -1939,7 +1939,12 @@ int dsl_slab_attach(dsl_handle* h, dsl_comm* comm, int lo_rank, int hi_rank, flo
     HIP_TRY(h, hipMemsetAsync(L->recv[k], 0, L->buf_floats * sizeof(float), h->stream));
   }
   if (int rc = dev_alloc(h, &L->dev_words, 4)) return rc;
-  HIP_TRY(h, hipStreamCreateWithFlags(&L->comm_stream, hipStreamNonBlocking));
+  {  // the transfer stream gets the highest priority: a hardware queue of its own (two plain streams may share
+     // one, and then the transfer kernels wait behind the interior force launch they are meant to run under)
+    int least = 0, greatest = 0;
+    HIP_TRY(h, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(h, hipStreamCreateWithPriority(&L->comm_stream, hipStreamNonBlocking, greatest));
+  }
   HIP_TRY(h, hipEventCreateWithFlags(&L->ev_pack, hipEventDisableTiming));
   HIP_TRY(h, hipEventCreateWithFlags(&L->ev_xfer, hipEventDisableTiming));
   if (L->overlap) {
@@ -2147,13 +2152,10 @@ int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
                                 L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x);
           }))
         return rc;
+      // the interior launch is queued BEHIND the pack and BEFORE the transfer is posted: the GPU goes straight from
+      // the pack into it, the transfer kernels (side stream, behind the pack's event) join it
       const auto t1 = std::chrono::steady_clock::now();
       HIP_TRY(h, hipEventRecord(L.ev_pack, h->stream));
-      HIP_TRY(h, hipStreamWaitEvent(L.comm_stream, L.ev_pack, 0));
-      const auto t2 = std::chrono::steady_clock::now();
-      if (int rc = link_post(h, L.comm_stream)) return rc;
-      const auto t3 = std::chrono::steady_clock::now();
-      HIP_TRY(h, hipEventRecord(L.ev_xfer, L.comm_stream));
       const auto t4 = std::chrono::steady_clock::now();
       if (int rc = run_segment(h, 1, [&]() -> int {
             h->split_pending = false;
@@ -2161,6 +2163,11 @@ int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
           }))
         return rc;
       const auto t5 = std::chrono::steady_clock::now();
+      HIP_TRY(h, hipStreamWaitEvent(L.comm_stream, L.ev_pack, 0));
+      const auto t2 = std::chrono::steady_clock::now();
+      if (int rc = link_post(h, L.comm_stream)) return rc;
+      const auto t3 = std::chrono::steady_clock::now();
+      HIP_TRY(h, hipEventRecord(L.ev_xfer, L.comm_stream));
       HIP_TRY(h, hipStreamWaitEvent(h->stream, L.ev_xfer, 0));
       const auto t6 = std::chrono::steady_clock::now();
       if (int rc = run_segment(h, 2, [&]() -> int { return link_append(h); })) return rc;
@@ -2169,7 +2176,7 @@ int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
       auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
       L.host_seg_s += sec(t0, t1) + sec(t4, t5) + sec(t6, t7);
       L.host_post_s += sec(t2, t3);
-      L.host_sync_s += sec(t1, t2) + sec(t3, t4) + sec(t5, t6);
+      L.host_sync_s += sec(t1, t4) + sec(t5, t2) + sec(t3, t6);
     }
     h->steps++;
     L.steps++;
