@@ -262,3 +262,43 @@ def test_grid_mode_equals_brute_force(n3):
         out.append((s.densities(), s.forces()))
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
+# ---- two particles, closed form -------------------------------------------------------------------
+def test_two_particles_closed_form():
+    """Two particles 0.5 h apart, every pass worked out by hand from the reference's formulas
+    (std_kernel.go:33-76, model.go:92-101, sph_field.go:155-200,251-269, fluid.go:127-197) in float64:
+    Density, LaplacianForce x mu (one neighbour: the running-sum x m quirk is a plain product), Gradient with the
+    pressures of FLUID_DENSITY = 87 (model.go:41) and Update.  Independent of the oracle's code paths: numbers only."""
+    PI = 3.141592653589
+    A, B, Ck = 315.0 / (64.0 * PI), -45.0 / PI, 90.0 / PI  # h = 1
+    prm = po.params_reference(4)
+    prm.neigh_mode = po.NEIGH_ALL
+    pos = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.0]], dtype=np.float32)
+    vel = np.array([[0.0, 0.0, 0.0], [0.2, 0.0, 0.0]], dtype=np.float32)
+    s = po.OracleSPH.from_state(prm, pos, vel=vel)
+    # D: rho = m F(0.5) = A (1 - 0.25)^2
+    s.density_all()
+    rho = A * 0.5625
+    assert np.allclose(s.densities(), [rho, rho], rtol=2e-7)
+    # V: F_0 = mu * ((v_1 - v_0) / rho_1) * O2D(0.5) * m, O2D = C (1 - 0.5); F_1 = -F_0
+    s.viscous_all()
+    fv = float(prm.mu) * (0.2 / rho) * (Ck * 0.5)
+    f = s.forces()
+    assert np.allclose(f[:, 0], [fv, -fv], rtol=1e-6) and np.all(f[:, 1:] == 0)
+    # G with rho = 100 > 87: P = (2.15/7.16) ((100/87)^7.16 - 1); grad_0 = dir * (-O1D) with dir = +x,
+    # O1D = B (1 - 0.5)^2; F = 2 P / rho^2; result = grad F rho m, ADDED to the force (fluid.go:168-169)
+    s.set_forces(np.zeros((2, 3), dtype=np.float32))
+    s.set_densities(np.array([100.0, 100.0], dtype=np.float32))
+    s.gradient_pressure_force()
+    P = (2.15 / 7.16) * ((100.0 / 87.0) ** 7.16 - 1.0)
+    g0 = (-(B * 0.25)) * (2.0 * P / 100.0 ** 2) * 100.0
+    f = s.forces()
+    assert np.allclose(f[:, 0], [g0, -g0], rtol=2e-6) and np.all(f[:, 1:] == 0)
+    assert g0 > 0  # the reference's sign: particle 0 is pushed TOWARDS its neighbour
+    # U: v += F/m dt, x += v dt, force reset (0, -9.81 m, 0), pressure 0 (dt = 0.01)
+    s.update()
+    v0 = g0 * 0.01
+    assert np.allclose(s.velocities()[:, 0], [v0, 0.2 - v0], rtol=2e-6)
+    assert np.allclose(s.positions()[:, 0], [v0 * 0.01, 0.5 + (0.2 - v0) * 0.01], rtol=2e-6, atol=1e-9)
+    assert np.allclose(s.forces(), [[0.0, -9.81, 0.0]] * 2) and np.all(s.pressures() == 0)
