@@ -870,10 +870,13 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // (a particle whose position has gone NaN -- the reference produces such next to boundary
             // particles -- is no one's neighbour there (dist < h is false); as a pad record it is none here
             // either, also in the runs that are walked without a mask)
-            if constexpr (EXACT) {  // raw values: rho itself, the reference divides by it pair by pair
+            if constexpr (EXACT) {
+              // raw values.  The reference forms 1/rho_j pair by pair (sph_field.go:262: Scale(.., 1/jDensity)); the
+              // quotient depends on j alone, so the very same IEEE division is done once per staged record instead
+              // (the XSPH sum divides the mass by rho_j: that instantiation keeps rho itself)
               if (real) {
                 a = make_float4(o[0], o[1], o[2], o[3]);
-                if constexpr (WANT_V || WANT_XS) b = make_float4(o[4], o[5], o[6], o[7]);
+                if constexpr (WANT_V || WANT_XS) b = make_float4(o[4], o[5], o[6], WANT_XS ? o[7] : 1.0f / o[7]);
               }
             } else if (real && o[0] == o[0] && o[1] == o[1] && o[2] == o[2]) {
               a = make_float4(o[0], o[1], o[2], o[3]);
@@ -1023,7 +1026,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 gz = gz + (in ? tz : 0.0f);
               }
               if constexpr (WANT_V) {
-                const float inv = 1.0f / b.w;
+                const float inv = WANT_XS ? 1.0f / b.w : b.w;
                 const float ux = (b.x - vx) * inv, uy = (b.y - vy) * inv, uz = (b.z - vz) * inv;
                 const float o2 = kern_O2D<false>(c, dist);
                 const float tx = ux * o2, ty = uy * o2, tz = uz * o2;
