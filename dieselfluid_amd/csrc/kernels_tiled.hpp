@@ -504,6 +504,9 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   // once the staging was down to three loads per lane: 0.794 ms with, 0.780 without, at 16M particles.)
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];
+  // EXACT: A holds the raw coordinates the exact walk needs, R the tile-relative records of the FAST test, which
+  // the candidate sweep uses as a conservative pre-filter (see below)
+  __shared__ float4 R[EXACT ? kTCap : 1];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   static_assert(!(EXACT && SHARE), "the exact sum is sequential: one lane per target");
   // (n_tiles is the base of the tile-list counters here; a slab always has half-empty ghost tiles: the host
@@ -542,16 +545,17 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
             o[2] = p.z[g];
           },
           [&](int slot, const float* o, bool real) {
-            if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
-              A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
-              return;
-            }
             float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
             if (real) {
               const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
               v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
             }
-            A[slot] = v;
+            if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
+              A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
+              R[slot] = v;
+            } else {
+              A[slot] = v;
+            }
           });
     }
     if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
@@ -578,6 +582,19 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
           const int lx = tile_target_cell(m, srow, off);
           const int pad_rec = m.row_lds[1] - kTPad;
           float density = 0.0f;
+          // The candidate sweep only has to find a SUPERSET of {dist < h}: the walk below forms the reference's
+          // own dist and applies the reference's own cut-off to every candidate it visits (one outside adds +0), and so
+          // does the force walk over the same masks.  So the sweep uses the FAST test on tile-relative records,
+          // q = 1 - r^2/h^2 in 4 operations, and keeps everything above -1e-3: its error is ~3e-5 for a target inside
+          // its tile (|x| <= 2.5 cells, candidates within 3.5).  A target far outside (a particle beyond the grid box,
+          // clamped into an edge cell) would lose that bound to cancellation: a wave with such a lane takes the
+          // exact r^2 test (one wave-uniform branch per chunk).
+          const float4 mer = R[own];
+          const float two_hh = 2.0f * c.inv_hh;
+          const float qsx = two_hh * mer.x, qsy = two_hh * mer.y, qsz = two_hh * mer.z, qa0 = 1.0f + mer.w;
+          const float reach = 4.0f * c.h;
+          const bool far_lane = !(fabsf(mer.x) <= reach && fabsf(mer.y) <= reach && fabsf(mer.z) <= reach);
+          const bool prefilter = __builtin_amdgcn_ballot_w64(far_lane) == 0ull;
           // SPHField.Density's loop body for one candidate record (sph_field.go:164-170): exactly the
           // operations of k_density<false>; a pad record or the particle itself adds +0
           auto add = [&](const float4& cnd, bool counts) {
@@ -600,12 +617,23 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
             for (int chunk = 0; j < je; ++chunk, j += 32) {
               const int jend = min(je, j + 32);
               unsigned int mask = 0u;
-              for (int jj = j; jj < jend; jj += 4) {
+              if (prefilter) {
+                for (int jj = j; jj < jend; jj += 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const float4 cnd = A[jj + u];
-                  const float dx = me.x - cnd.x, dy = me.y - cnd.y, dz = me.z - cnd.z;
-                  mask_push_lt(mask, dist2<false>(dx, dy, dz), c.r2_thr);
+                  for (int u = 0; u < 4; ++u) {
+                    const float4 cnd = R[jj + u];
+                    const float t = __builtin_fmaf(cnd.z, qsz, __builtin_fmaf(cnd.y, qsy, __builtin_fmaf(cnd.x, qsx, cnd.w + qa0)));
+                    mask_push_lt(mask, -1.0e-3f, t);
+                  }
+                }
+              } else {
+                for (int jj = j; jj < jend; jj += 4) {
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const float4 cnd = A[jj + u];
+                    const float dx = me.x - cnd.x, dy = me.y - cnd.y, dz = me.z - cnd.z;
+                    mask_push_lt(mask, dist2<false>(dx, dy, dz), c.r2_thr);
+                  }
                 }
               }
               // the sweep tests whole groups of 4: the up to 3 records behind the run belong to a cell the
