@@ -1,9 +1,11 @@
 #!/bin/bash
-# per-kernel durations of a developed flow (2M particles after 6000 steps): the last 200 steps of a rocprofv3 kernel trace
+# per-kernel durations of a developed flow: tools/gpu_dev_trace.sh [n3=126] [steps=6000]; steps 200-400 and the last 200
+# steps of a rocprofv3 kernel trace of tools/long_run.py
 out=$GRAFT_REPO_ROOT/gpurun_out/r2; mkdir -p $out
+N3=${1:-126}; STEPS=${2:-6000}
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/devtrace
-rocprofv3 --kernel-trace --output-format csv -d /tmp/devtrace -- python3 $GRAFT_REPO_ROOT/tools/long_run.py 126 6000 2000 > /dev/null 2> $out/devtrace.err
-python3 - <<'PY'
+rocprofv3 --kernel-trace --output-format csv -d /tmp/devtrace -- python3 $GRAFT_REPO_ROOT/tools/long_run.py $N3 $STEPS $STEPS > /dev/null 2> $out/devtrace.err
+python3 - <<'PY' | tee $out/devtrace_${N3}.txt
 import csv, glob, collections, os
 f = glob.glob('/tmp/devtrace/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
