@@ -48,8 +48,12 @@ def parse():
                     help="N=1 WCSPH only: after the timed region advance this many steps (the column collapses, the "
                          "lattice melts: ~10000 steps = 0.45 s of flow at n3=252) and time 20 more; reported as "
                          "developed_ms_per_step beside the headline.  0 = skip")
-    ap.add_argument("--cpu-n3", type=int, default=64, help="edge of the CPU-baseline sample block")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--exact-steps", type=int, default=5,
+                    help="N=1 WCSPH, --math fast only: also time this many steps of the SAME scene in DSL_MATH_EXACT (the "
+                         "mode that is bit for bit the oracle's) on a second engine; reported under `exact`.  0 = skip")
+    ap.add_argument("--cpu-n3", type=int, default=100,
+                    help="edge of the CPU-baseline sample block (100 = BASELINE configs[1]'s 1M particles)")
+    ap.add_argument("--cpu-steps", type=int, default=1)
     return ap.parse_args()
 
 
@@ -74,7 +78,7 @@ def cpu_baseline(args):
         "unit": "M particle-steps/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"same dam-break scene at n3={n3} ({n3**3} particles), {args.cpu_steps} WCSPH steps, "
+        "sample": f"same dam-break scene at n3={n3} ({n3**3} particles), {args.cpu_steps} WCSPH step(s), "
                   f"{dt:.1f} s of CPU; oracle/dsl_oracle.c single thread",
     }
 
@@ -144,9 +148,14 @@ def main():
         # engine kernels, RCCL calls and torch's own small ops are ordered through torch's current
         # stream: give it a stream of its own instead of the legacy default stream
         torch.cuda.set_stream(torch.cuda.Stream(torch.device("cuda", local_rank)))
+        # the library drives the slab step (RCCL inside libdslsph.so); DSL_BENCH_SLAB_DRIVER=python keeps the
+        # torch.distributed protocol of slab.py, =native forces the library driver also in a gloo rehearsal
+        # (its transport calls then go through the host-staged table, engine.HostStagedComm)
+        which = os.environ.get("DSL_BENCH_SLAB_DRIVER", "")
         drv = slab.SlabDriver.dambreak(n3, math_mode=math_mode, device=local_rank, pcisph=pci,
                                        params_hook=pci_params if pci else None,
-                                       overlap=False if args.no_overlap else None)
+                                       overlap=False if args.no_overlap else None,
+                                       native={"python": False, "native": True}.get(which))
         step = drv.pcisph_step if pci else drv.wcsph_step
         engines = [drv.engine_core]
 
@@ -223,6 +232,30 @@ def main():
                    if args.method == "wcsph" else
                    ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
                     "pci_predict", "pci_density", "update"))}
+    exact = None
+    if world == 1 and args.method == "wcsph" and args.math == "fast" and args.exact_steps > 0:
+        # the same scene on a second engine in DSL_MATH_EXACT: the reference's own float32 operations in the
+        # reference's order (every EXACT parity test is array_equal against the oracle), driver-reproducible
+        for e in engines:
+            e.timing_enable(False)
+        pe, pos_e = scenes.dambreak_scene(n3, math_mode=0)
+        xe = SPHEngine(pe, device=local_rank)
+        xe.upload("positions", pos_e)
+        xe.reset_forces()
+        del pos_e
+        xe.wcsph_step(2)
+        xe.timing_reset()
+        xe.timing_enable(2)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        xe.wcsph_step(args.exact_steps)
+        torch.cuda.synchronize()
+        te = (time.perf_counter() - te) / args.exact_steps
+        exact = {"value": round(n_total / te / 1e6, 3), "ms_per_step": round(te * 1e3, 4), "steps": args.exact_steps,
+                 "warmup": 2, "kernels_ms": {k: round(xe.timing(k)[0], 4) for k in ("density", "force_integrate")},
+                 "math": "exact (bit for bit the CPU oracle's results; tests/test_gpu_parity.py)"}
+        xe.close()
+        del xe
     developed = None
     if world == 1 and args.method == "wcsph" and args.developed_steps > 0:
         # the headline above is the contract's configuration (the jittered lattice: exactly 8 per cell);
@@ -306,8 +339,11 @@ def main():
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,
             "developed": developed,
+            "exact": exact,
             "n_live_rank0": n_live,
-            "slab_driver": ("native (dsl_slab_wcsph_step: RCCL inside libdslsph.so)" if world > 1 and getattr(drv, "native", False)
+            "slab_driver": (("native (dsl_slab_wcsph_step: RCCL inside libdslsph.so)" if backend == "nccl" else
+                             "native (dsl_slab_wcsph_step over a host-staged dsl_comm_create_custom transport)")
+                            if world > 1 and getattr(drv, "native", False)
                             else ("python protocol" if world > 1 else None)),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -122,7 +122,11 @@ func (e *Engine) AddBoundaryParticles(positions []float32) error {
 	if len(positions) == 0 {
 		return nil
 	}
-	return e.ck(C.dsl_add_boundary_particles(e.h, (*C.float)(unsafe.Pointer(&positions[0])), C.size_t(len(positions))))
+	if err := e.ck(C.dsl_add_boundary_particles(e.h, (*C.float)(unsafe.Pointer(&positions[0])), C.size_t(len(positions)))); err != nil {
+		return err
+	}
+	// the library's n_boundary has grown: refresh the copy that SetParams sends back and that sizes the buffers
+	return e.ck(C.dsl_get_params(e.h, &e.Params))
 }
 
 // ---- the SPHField operators no solver calls (model/field/sph_field.go:124-135,203-294) ----
@@ -197,6 +201,17 @@ func NewComm(nranks, rank int, id [128]byte, device int) (*Comm, error) {
 	return c, nil
 }
 func (c *Comm) Close() { C.dsl_comm_destroy(c.c); c.c = nil }
+
+// NewCommCustom: a communicator over the host's own transport (MPI, sockets, ...) instead of RCCL.  The table's
+// callbacks are C function pointers (exported Go functions via //export, or plain C); the library calls them in
+// exactly the order it would call RCCL (dsl_transport in include/dslsph.h).
+func NewCommCustom(nranks, rank, device int, table *C.dsl_transport) (*Comm, error) {
+	c := &Comm{}
+	if rc := C.dsl_comm_create_custom(C.int(nranks), C.int(rank), C.int(device), table, &c.c); rc != 0 {
+		return nil, errors.New(C.GoString(C.dsl_comm_last_error()))
+	}
+	return c, nil
+}
 
 // NewEngines: one process, several devices (dsl_create_multi: handles + ncclCommInitAll).  Drive each Engine
 // from its own goroutine under runtime.LockOSThread: RCCL wants one host thread per device.

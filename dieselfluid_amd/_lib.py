@@ -9,8 +9,11 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-# DSL_LIB: load another build of the same library (diagnostic builds, e.g. -DDSL_DIAG_STAMPS)
-_LIB = os.environ.get("DSL_LIB") or os.path.join(_PKG, "lib", "libdslsph.so")
+_BUILT = os.path.join(_PKG, "lib", "libdslsph.so")  # what build_library() makes, always
+# DSL_LIB: LOAD another build of the same library (A/B variants, diagnostic builds such as -DDSL_DIAG_STAMPS).
+# It never redirects the build: a default-flags rebuild over a variant would make an A/B run measure the same
+# code twice without noticing.
+_LIB = os.environ.get("DSL_LIB") or _BUILT
 _SRC_DIR = os.path.join(_PKG, "csrc")
 _HDR = os.path.join(_ROOT, "include", "dslsph.h")
 
@@ -52,6 +55,17 @@ class Stats(C.Structure):
         ("max_vel", C.c_float), ("max_f", C.c_float), ("pci_max_error", C.c_float), ("pci_iters", C.c_int32),
         ("steps", C.c_int64), ("grid_dims", C.c_int32 * 3), ("grid_cells", C.c_int32), ("max_cell_count", C.c_int32),
     ]
+
+
+# dsl_transport (include/dslsph.h): the host's own transport behind dsl_comm_create_custom
+TR_GROUP = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TR_XFER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+TR_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("group_start", TR_GROUP), ("group_end", TR_GROUP), ("send", TR_XFER),
+                ("recv", TR_XFER), ("all_reduce_max_u32", TR_REDUCE)]
 
 
 # every symbol include/dslsph.h declares: name -> (restype, argtypes)
@@ -112,6 +126,7 @@ EXPORTS = {
     "dsl_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "dsl_comm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(_vp)]),
     "dsl_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "dsl_comm_create_custom": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "dsl_comm_destroy": (C.c_int, [_vp]),
     "dsl_comm_last_error": (C.c_char_p, []),
     "dsl_create_multi": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -140,15 +155,15 @@ def _sources():
 def build_library(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 ... -> dieselfluid_amd/lib/libdslsph.so (in-tree)."""
     deps = _sources() + [_HDR]
-    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(d) for d in deps):
-        return _LIB
+    if not force and os.path.exists(_BUILT) and all(os.path.getmtime(_BUILT) >= os.path.getmtime(d) for d in deps):
+        return _BUILT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise DslError("hipcc not found: cannot build libdslsph.so (no fallback exists)")
-    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", _LIB, os.path.join(_SRC_DIR, "dslsph.hip")]
+    os.makedirs(os.path.dirname(_BUILT), exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", _BUILT, os.path.join(_SRC_DIR, "dslsph.hip")]
     subprocess.check_call(cmd)
-    return _LIB
+    return _BUILT
 
 
 _lib = None

@@ -88,6 +88,12 @@ struct dsl_handle {
   DevStats* dstats = nullptr;
   int cur_pv = 0, cur_ids = 0, cur_f = 0, cur_pci = 0;
   bool grid_valid = false, forces_uniform = false, press_zero = true, pci_active = false, dens_fresh = false;
+  // dens_held: rho / pterm hold per-particle values in the CURRENT slot order (possibly stale ones: after a mass
+  // change or new boundary particles the reference, too, keeps the old density on the same particle until the
+  // next DensityAll), so a sort has to carry them.  dens_fresh: they also belong to the current positions / mass.
+  bool dens_held = false;
+  // the histogram / "cells to order" bitmap were handed to a build that may not have cleaned them again
+  bool sort_scratch_dirty = false;
   int64_t steps = 0;
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
@@ -330,6 +336,11 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   // (the histogram and the "cells to order" bitmap are clean: zeroed at creation, and again by
   // k_scan_apply / k_tile_list of the previous build)
   const bool ordered = !h->prm.sort_unordered;
+  if (h->sort_scratch_dirty) {  // an earlier build stopped between k_cell_rank and the kernels that clean up behind it
+    HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+    if (h->unordered) HIP_TRY(h, hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream));
+  }
+  h->sort_scratch_dirty = true;
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                        ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered);
@@ -365,7 +376,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   a.ids_dst = h->ids[h->cur_ids ^ 1];
   // derived arrays (an explicit dsl_build_neighbours behind a density pass: rare) follow through the
   // particles' final slots, which the scatter leaves in place of the ranks
-  float* derived[3] = {(carry_derived && h->dens_fresh) ? h->rho : nullptr, (carry_derived && h->dens_fresh) ? h->pterm : nullptr,
+  float* derived[3] = {(carry_derived && h->dens_held) ? h->rho : nullptr, (carry_derived && h->dens_held) ? h->pterm : nullptr,
                        (carry_derived && !h->press_zero) ? h->press : nullptr};
   const bool want_dest = derived[0] || derived[1] || derived[2];
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work),
@@ -386,6 +397,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     }
   } else {
     h->dens_fresh = false;
+    h->dens_held = false;
   }
   h->cur_pv ^= 1;
   h->cur_ids ^= 1;
@@ -402,7 +414,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
                          h->cell_start, h->tiles, h->n_tiles, h->tile_desc);
     });
     if (rc) return rc;
-
+    h->sort_scratch_dirty = false;  // k_scan_apply and k_tile_list are queued: they leave both arrays clean
   }
   if (h->c.n_ptr && h->lsh) {
     // the sort has dropped the stale ghosts; the live count stays on the device (otherwise k_tile_list did it)
@@ -456,7 +468,7 @@ int density_pass(dsl_handle* h) {
 #undef DSL_LAUNCH_DENSITY
     });
     if (rc) return rc;
-    h->dens_fresh = true;
+    h->dens_fresh = h->dens_held = true;
     h->masks_valid = true;  // until positions or the slot order change
     return DSL_OK;
   }
@@ -472,7 +484,7 @@ int density_pass(dsl_handle* h) {
       });
   });
   if (rc) return rc;
-  h->dens_fresh = true;
+  h->dens_fresh = h->dens_held = true;
   if (xt) h->masks_valid = true;
   return DSL_OK;
 }
@@ -929,6 +941,9 @@ int dsl_set_params(dsl_handle* h, const dsl_params* p) {
   if (p->n_particles != h->prm.n_particles || p->capacity != h->prm.capacity || c.ncell != h->c.ncell ||
       c.dims[0] != h->c.dims[0] || c.dims[1] != h->c.dims[1] || c.dims[2] != h->c.dims[2] || c.h != h->c.h)
     return fail(h, DSL_ERR_INVALID, "dsl_set_params: n_particles, capacity, h and the grid box are fixed at creation");
+  if (p->n_boundary != h->nb)
+    return fail(h, DSL_ERR_INVALID,
+                "dsl_set_params: n_boundary must be the current boundary count (dsl_get_params after dsl_add_boundary_particles)");
   c.n = h->c.n;  // live count (slab mode changes it)
   c.slab_axis = h->c.slab_axis;
   c.slab_lo = h->c.slab_lo;
@@ -947,8 +962,10 @@ int dsl_set_params(dsl_handle* h, const dsl_params* p) {
   h->prm = *p;
   h->c = c;
   if (mass_changed) {
-    h->dens_fresh = false;  // densities (and P/rho^2) are stale: the next pass that needs them must follow a density pass
-  } else if (eos_changed && h->dens_fresh) {
+    // densities (and P/rho^2) are stale -- like the reference's, which keeps the old value on the same particle until
+    // the next DensityAll: they stay held (a sort still carries them), they are just no longer fresh
+    h->dens_fresh = false;
+  } else if (eos_changed && h->dens_held) {
     dim3 g(grid_for(launch_n(h))), b(kBlock);
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_pterm<decltype(fast)::value>), g, b, 0, h->stream, h->c, bnd_of(h), h->rho, h->pterm);
@@ -1023,7 +1040,7 @@ int dsl_upload(dsl_handle* h, int buffer, const float* host, size_t count) {
       by_math(h, [&](auto fast) {
         hipLaunchKernelGGL((k_pterm<decltype(fast)::value>), g, b, 0, h->stream, h->c, bnd_of(h), h->rho, h->pterm);
       });
-      h->dens_fresh = true;
+      h->dens_fresh = h->dens_held = true;
       break;
     case DSL_BUF_PRESSURES:
       hipLaunchKernelGGL(k_unpack1, g, b, 0, h->stream, h->n, h->stage, ids, h->press, limit);
@@ -1069,7 +1086,7 @@ int dsl_add_boundary_particles(dsl_handle* h, const float* host_positions, size_
     pciv = mpciv(h);
   }
   hipLaunchKernelGGL(k_append_boundary, dim3(grid_for(nb)), dim3(kBlock), 0, h->stream, nb, h->n, h->n, n_fluid, h->stage,
-                     p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], pcip, pciv);
+                     p.x, p.y, p.z, v.x, v.y, v.z, h->ids[h->cur_ids], pcip, pciv, h->rho, h->pterm);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->n += nb;
@@ -1078,6 +1095,8 @@ int dsl_add_boundary_particles(dsl_handle* h, const float* host_positions, size_
   h->prm.n_boundary += nb;
   h->grid_valid = false;
   h->masks_valid = false;
+  // the fluid's densities are stale now (new neighbours) but still sit on their particles: the next sort carries
+  // them, the appended slots read as Get() reads a boundary particle (rho = 0, P/rho^2 = 0/0)
   h->dens_fresh = false;
   return DSL_OK;
 }
@@ -1719,6 +1738,7 @@ static int slab_append_shifted(dsl_handle* h, const float* dev_message_a, const 
   HIP_TRY(h, hipGetLastError());
   h->grid_valid = false;
   h->dens_fresh = false;
+  h->dens_held = false;  // (the appended records have no densities yet; the slab step's sort does not carry them)
   return DSL_OK;
 }
 
@@ -1854,9 +1874,26 @@ int dsl_comm_create_all(int ndev, const int* devices, dsl_comm** out) {
   return DSL_OK;
 }
 
+int dsl_comm_create_custom(int nranks, int rank, int device, const dsl_transport* t, dsl_comm** out) {
+  if (!out || !t || nranks < 1 || rank < 0 || rank >= nranks || !t->group_start || !t->group_end || !t->send || !t->recv ||
+      !t->all_reduce_max_u32) {
+    g_comm_error = "dsl_comm_create_custom: bad argument (every callback of dsl_transport is required)";
+    return DSL_ERR_INVALID;
+  }
+  dsl_comm* c = new (std::nothrow) dsl_comm();
+  if (!c) return DSL_ERR_NOMEM;
+  c->custom = true;
+  c->tr = *t;
+  c->nranks = nranks;
+  c->rank = rank;
+  c->device = device;
+  *out = c;
+  return DSL_OK;
+}
+
 int dsl_comm_destroy(dsl_comm* c) {
   if (!c) return DSL_OK;
-  if (c->comm && rccl().lib) (void)rccl().CommDestroy(c->comm);
+  if (c->comm && !c->custom && rccl().lib) (void)rccl().CommDestroy(c->comm);
   delete c;
   return DSL_OK;
 }
@@ -1959,24 +1996,26 @@ namespace {
 int link_post(dsl_handle* h, hipStream_t st) {
   SlabLink& L = *h->link;
   if (L.lo < 0 && L.hi < 0) return DSL_OK;
-  RcclApi& a = rccl();
   const size_t n = dsl_slab_message_floats_for(h, L.cap_full, L.cap_x);
-  ncclComm_t comm = L.comm->comm;
-  NCCL_TRY_H(h, a.GroupStart());
-  if (L.lo >= 0) NCCL_TRY_H(h, a.Send(L.send[0], n, ncclFloat, L.lo, comm, st));
-  if (L.hi >= 0) NCCL_TRY_H(h, a.Send(L.send[1], n, ncclFloat, L.hi, comm, st));
+  dsl_comm* comm = L.comm;
+  if (int rc = xfer_group_start(h, comm)) return rc;
+  if (L.lo >= 0)
+    if (int rc = xfer_send(h, comm, L.send[0], n, L.lo, st)) return rc;
+  if (L.hi >= 0)
+    if (int rc = xfer_send(h, comm, L.send[1], n, L.hi, st)) return rc;
   // two messages between the same pair of ranks (two ranks with periodic images, or a rank that is
   // its own neighbour in a test) are matched in issue order: the peer's LOW band arrives from above
   const bool same_peer = L.lo >= 0 && L.lo == L.hi;
   if (same_peer) {
-    NCCL_TRY_H(h, a.Recv(L.recv[1], n, ncclFloat, L.hi, comm, st));
-    NCCL_TRY_H(h, a.Recv(L.recv[0], n, ncclFloat, L.lo, comm, st));
+    if (int rc = xfer_recv(h, comm, L.recv[1], n, L.hi, st)) return rc;
+    if (int rc = xfer_recv(h, comm, L.recv[0], n, L.lo, st)) return rc;
   } else {
-    if (L.lo >= 0) NCCL_TRY_H(h, a.Recv(L.recv[0], n, ncclFloat, L.lo, comm, st));
-    if (L.hi >= 0) NCCL_TRY_H(h, a.Recv(L.recv[1], n, ncclFloat, L.hi, comm, st));
+    if (L.lo >= 0)
+      if (int rc = xfer_recv(h, comm, L.recv[0], n, L.lo, st)) return rc;
+    if (L.hi >= 0)
+      if (int rc = xfer_recv(h, comm, L.recv[1], n, L.hi, st)) return rc;
   }
-  NCCL_TRY_H(h, a.GroupEnd());
-  return DSL_OK;
+  return xfer_group_end(h, comm);
 }
 
 int link_append(dsl_handle* h) {
@@ -2008,7 +2047,7 @@ int link_replan(dsl_handle* h) {
   if (int rc = dsl_slab_status(h, st, 1)) return rc;
   if (L.comm && L.comm->nranks > 1) {
     HIP_TRY(h, hipMemcpyAsync(L.dev_words, st, sizeof(st), hipMemcpyHostToDevice, h->stream));
-    NCCL_TRY_H(h, rccl().AllReduce(L.dev_words, L.dev_words, 4, ncclInt32, ncclMax, L.comm->comm, h->stream));
+    if (int rc = xfer_all_reduce_max(h, L.comm, L.dev_words, 4, h->stream)) return rc;  // (counts: never negative)
     HIP_TRY(h, hipMemcpyAsync(st, L.dev_words, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
@@ -2204,8 +2243,7 @@ int dsl_slab_pcisph_step(dsl_handle* h, int nsteps) {
       // the early-out of pcisph_darwin.go:95-98 is decided by the maximum over all ranks: the error
       // word holds a non-negative float, whose bits order like an unsigned integer
       if (reduce)
-        NCCL_TRY_H(h, rccl().AllReduce(&h->dstats->pci_cur_err_bits, &h->dstats->pci_cur_err_bits, 1, ncclUint32, ncclMax,
-                                        L.comm->comm, h->stream));
+        if (int rc = xfer_all_reduce_max(h, L.comm, &h->dstats->pci_cur_err_bits, 1, h->stream)) return rc;
       if (int rc = pci_check(h)) return rc;
     }
     h->pci_split_guard = false;

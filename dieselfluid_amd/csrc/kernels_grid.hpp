@@ -289,10 +289,13 @@ __global__ __launch_bounds__(kBlock) void k_append_boundary(int nb, int at, int 
                                                             float* __restrict__ y, float* __restrict__ z,
                                                             float* __restrict__ vx, float* __restrict__ vy,
                                                             float* __restrict__ vz, int* __restrict__ ids, Soa3 pcip,
-                                                            Soa3 pciv) {
+                                                            Soa3 pciv, float* __restrict__ rho,
+                                                            float* __restrict__ pterm) {
   const int k = blockIdx.x * kBlock + threadIdx.x;
   if (k >= nb) return;
   const int d = at + k;
+  rho[d] = 0.0f;  // as ParticleArray.Get reads a boundary particle (particle_array.go:94-117): density 0, P/rho^2 = 0/0
+  pterm[d] = __uint_as_float(0x7fc00000u);
   const bool zero = first_id + k == zero_id;
   const float px = zero ? 0.0f : stage[3 * k], py = zero ? 0.0f : stage[3 * k + 1], pz = zero ? 0.0f : stage[3 * k + 2];
   x[d] = px;

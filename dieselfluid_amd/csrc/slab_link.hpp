@@ -14,6 +14,8 @@
 struct dsl_comm {
   ncclComm_t comm = nullptr;
   int nranks = 0, rank = 0, device = 0;
+  bool custom = false;  // dsl_comm_create_custom: the host's transport table instead of RCCL
+  dsl_transport tr{};
   std::string err;
 };
 
@@ -84,6 +86,56 @@ std::string g_comm_error;
     ncclResult_t r__ = (expr);                                                                          \
     if (r__ != ncclSuccess) return fail((h), DSL_ERR_DEVICE, std::string(#expr) + ": " + rccl().GetErrorString(r__)); \
   } while (0)
+
+// The slab drivers' transport calls: RCCL, or the host's table (dsl_comm_create_custom) -- the SAME call
+// sequence either way, which is what lets the N > 1 protocol (message order between distinct ranks, the
+// re-plan and PCISPH all-reduces) run in tests on a box where RCCL cannot (several ranks on one device).
+// The all-reduce words are non-negative (status counts, the bits of a non-negative float): signed and
+// unsigned MAX agree on them.
+#define XFER_TRY_H(h, expr, what)                                                                        \
+  do {                                                                                                   \
+    if ((expr) != 0) return fail((h), DSL_ERR_DEVICE, std::string("transport callback failed: ") + (what)); \
+  } while (0)
+inline int xfer_group_start(dsl_handle* h, dsl_comm* c) {
+  if (c->custom) {
+    XFER_TRY_H(h, c->tr.group_start(c->tr.ctx), "group_start");
+    return DSL_OK;
+  }
+  NCCL_TRY_H(h, rccl().GroupStart());
+  return DSL_OK;
+}
+inline int xfer_group_end(dsl_handle* h, dsl_comm* c) {
+  if (c->custom) {
+    XFER_TRY_H(h, c->tr.group_end(c->tr.ctx), "group_end");
+    return DSL_OK;
+  }
+  NCCL_TRY_H(h, rccl().GroupEnd());
+  return DSL_OK;
+}
+inline int xfer_send(dsl_handle* h, dsl_comm* c, const float* buf, size_t n, int peer, hipStream_t st) {
+  if (c->custom) {
+    XFER_TRY_H(h, c->tr.send(c->tr.ctx, buf, n * sizeof(float), peer, (void*)st), "send");
+    return DSL_OK;
+  }
+  NCCL_TRY_H(h, rccl().Send(buf, n, ncclFloat, peer, c->comm, st));
+  return DSL_OK;
+}
+inline int xfer_recv(dsl_handle* h, dsl_comm* c, float* buf, size_t n, int peer, hipStream_t st) {
+  if (c->custom) {
+    XFER_TRY_H(h, c->tr.recv(c->tr.ctx, buf, n * sizeof(float), peer, (void*)st), "recv");
+    return DSL_OK;
+  }
+  NCCL_TRY_H(h, rccl().Recv(buf, n, ncclFloat, peer, c->comm, st));
+  return DSL_OK;
+}
+inline int xfer_all_reduce_max(dsl_handle* h, dsl_comm* c, void* words, size_t count, hipStream_t st) {
+  if (c->custom) {
+    XFER_TRY_H(h, c->tr.all_reduce_max_u32(c->tr.ctx, words, count, (void*)st), "all_reduce_max_u32");
+    return DSL_OK;
+  }
+  NCCL_TRY_H(h, rccl().AllReduce(words, words, count, ncclUint32, ncclMax, c->comm, st));
+  return DSL_OK;
+}
 
 }  // namespace
 

@@ -72,6 +72,108 @@ class Comm:
             pass
 
 
+class HostStagedComm(Comm):
+    """dsl_comm over the host's OWN transport (dsl_comm_create_custom, include/dslsph.h): the library makes
+    the same call sequence as it makes to RCCL (group_start / send, recv per neighbour / group_end;
+    all_reduce_max for the re-plan words and the PCISPH iteration error), and this table moves the messages
+    through host memory with torch.distributed (gloo).  It exists for the places RCCL cannot go -- several
+    ranks on ONE device (the 2- and 3-rank GPU tests of the library's step drivers, gloo rehearsals of
+    bench.py --gpus N) -- and doubles as the worked example of a host-supplied transport.  Blocking: every
+    operation synchronises the stream it is ordered on."""
+
+    def __init__(self, nranks: int, rank: int, device: int, group=None):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from ._lib import TR_GROUP, TR_REDUCE, TR_XFER, Transport
+        self._L = load_library()
+        self.ptr = C.c_void_p()
+        self.nranks, self.rank = int(nranks), int(rank)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipSetDevice.argtypes = [C.c_int]
+        H2D, D2H = 1, 2
+        state = {"ops": None, "calls": []}
+        self.calls = state["calls"]  # (tests) the sequence of transport calls the library made
+
+        def run(ops):
+            hip.hipSetDevice(int(device))
+            for st in {o[4] for o in ops}:
+                if hip.hipStreamSynchronize(st):
+                    return 1
+            works, recvs, keep = [], [], []
+            for kind, buf, nbytes, peer, _st in ops:
+                t = torch.empty(nbytes, dtype=torch.uint8)
+                keep.append(t)
+                if kind == "send":
+                    if hip.hipMemcpy(t.data_ptr(), buf, nbytes, D2H):
+                        return 1
+                    works.append(dist.P2POp(dist.isend, t, peer, group=group))
+                else:
+                    works.append(dist.P2POp(dist.irecv, t, peer, group=group))
+                    recvs.append((t, buf, nbytes))
+            for w in dist.batch_isend_irecv(works):
+                w.wait()
+            for t, buf, nbytes in recvs:
+                if hip.hipMemcpy(buf, t.data_ptr(), nbytes, H2D):
+                    return 1
+            return 0
+
+        def guarded(fn):
+            def call(*a):
+                try:
+                    return int(fn(*a))
+                except Exception as e:  # an exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    self.error = e
+                    return 1
+            return call
+
+        def group_start(_ctx):
+            state["calls"].append("group_start")
+            state["ops"] = []
+            return 0
+
+        def group_end(_ctx):
+            state["calls"].append("group_end")
+            ops, state["ops"] = state["ops"], None
+            return run(ops) if ops else 0
+
+        def xfer(kind):
+            def f(_ctx, buf, nbytes, peer, stream):
+                state["calls"].append((kind, int(peer), int(nbytes)))
+                op = (kind, buf, int(nbytes), int(peer), stream)
+                if state["ops"] is None:
+                    return run([op])
+                state["ops"].append(op)
+                return 0
+            return f
+
+        def all_reduce(_ctx, buf, count, stream):
+            state["calls"].append(("all_reduce_max", int(count)))
+            hip.hipSetDevice(int(device))
+            if hip.hipStreamSynchronize(stream):
+                return 1
+            a = np.zeros(int(count), dtype=np.uint32)
+            if hip.hipMemcpy(a.ctypes.data, buf, a.nbytes, D2H):
+                return 1
+            t = torch.from_numpy(a.astype(np.int64))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            a = t.numpy().astype(np.uint32)
+            return 1 if hip.hipMemcpy(buf, a.ctypes.data, a.nbytes, H2D) else 0
+
+        # (the CFUNCTYPE objects must outlive the communicator: the library keeps the raw pointers)
+        self._cb = (TR_GROUP(guarded(group_start)), TR_GROUP(guarded(group_end)), TR_XFER(guarded(xfer("send"))),
+                    TR_XFER(guarded(xfer("recv"))), TR_REDUCE(guarded(all_reduce)))
+        self._table = Transport(None, *self._cb)
+        rc = self._L.dsl_comm_create_custom(self.nranks, self.rank, int(device), C.cast(C.byref(self._table), C.c_void_p),
+                                            C.byref(self.ptr))
+        if rc:
+            raise DslError(f"dsl_comm_create_custom failed ({rc}): {self._L.dsl_comm_last_error().decode()}")
+
+
 class SPHEngine:
     def __init__(self, params: Params, device: int = 0):
         self._L = load_library()

@@ -208,7 +208,10 @@ class SPH {
     std::vector<float> colliderPositions;
     for (mesh::Mesh* m : colliders) {
       colliderPositions = m->GenerateBoundaryParticles(2.0f);
-      if (!colliderPositions.empty()) ck(dsl_add_boundary_particles(h_, colliderPositions.data(), colliderPositions.size()));
+      if (!colliderPositions.empty()) {
+        ck(dsl_add_boundary_particles(h_, colliderPositions.data(), colliderPositions.size()));
+        ck(dsl_get_params(h_, &prm_));  // n_boundary has grown: dsl_set_params wants the current count back
+      }
       boundary_ += (int)colliderPositions.size() / 3;
     }
     return colliderPositions;

@@ -239,9 +239,13 @@ class SlabDriver:
     def attach_native(self, comm=None, lo_rank=None, hi_rank=None):
         """Hands the whole slab step to the library: the RCCL group send/recv, the split step, the
         re-plan.  This driver is then a thin caller (wcsph_step / pcisph_step are one C call each)."""
-        from .engine import Comm
+        from .engine import Comm, HostStagedComm
         core = self.engine_core
-        if comm is None and self.world > 1:
+        if comm is None and self.world > 1 and self.backend != "nccl":
+            # no RCCL between these ranks (gloo: several ranks on one device, CPU rehearsals): the library drives
+            # the very same step, its transport calls go through the host's table (dsl_comm_create_custom)
+            comm = HostStagedComm(self.world, self.rank, core.device, group=self.group)
+        elif comm is None and self.world > 1:
             def bcast(raw):
                 objs = [raw]
                 dist.broadcast_object_list(objs, src=0, group=self.group)

@@ -376,6 +376,23 @@ int dsl_comm_create(int nranks, int rank, const uint8_t id[DSL_COMM_ID_BYTES], i
 int dsl_comm_create_all(int ndev, const int *devices, dsl_comm **out /* ndev */);
 int dsl_comm_destroy(dsl_comm *c);
 const char *dsl_comm_last_error(void);
+/* A communicator over the HOST'S OWN transport instead of RCCL (MPI, a socket layer, a test shim): the slab
+ * drivers make exactly the same sequence of calls through this table as they make to RCCL (one group per
+ * exchange: group_start, send per neighbour, recv per neighbour, group_end; all_reduce_max for the re-plan
+ * words and the PCISPH iteration error).  Buffers are DEVICE pointers; `stream` is the hipStream_t the
+ * operation is ordered on: it may start only once the work queued on that stream so far has finished, and
+ * work queued on the stream after the call returns must see its result (RCCL's stream semantics; a blocking
+ * implementation satisfies them by synchronising the stream first).  Inside a group nothing may block on
+ * its peer before group_end.  Every callback returns 0 on success; the table is copied. */
+typedef struct dsl_transport {
+  void *ctx;
+  int (*group_start)(void *ctx);
+  int (*group_end)(void *ctx);
+  int (*send)(void *ctx, const void *dev_buf, size_t bytes, int peer, void *stream);
+  int (*recv)(void *ctx, void *dev_buf, size_t bytes, int peer, void *stream);
+  int (*all_reduce_max_u32)(void *ctx, void *dev_buf /* in place */, size_t count, void *stream);
+} dsl_transport;
+int dsl_comm_create_custom(int nranks, int rank, int device, const dsl_transport *transport, dsl_comm **out);
 int dsl_create_multi(const dsl_params *params /* ndev */, int ndev, const int *devices, dsl_handle **handles /* ndev */,
                      dsl_comm **comms /* ndev */);
 int dsl_slab_attach(dsl_handle *h, dsl_comm *comm, int lo_rank, int hi_rank, float width_full, float width, int cap_full,

@@ -170,3 +170,56 @@ def test_fused_step_with_boundary_particles(math_mode):
     else:
         assert helpers.rel_err(gx[:n][~bad], ox[~bad]) < 1e-5
     eng.close()
+
+
+def test_stale_densities_stay_on_their_particles():
+    """new boundary particles (or a new mass) leave the densities stale, not scrambled -- the reference keeps
+    the old value on the same particle until the next DensityAll (particle_array.go:94-117 reads whatever
+    `densities[i]` holds).  A neighbour build in between moves the particles; their densities must move with them.
+    The appended slots read as Get() reads a boundary particle."""
+    from dieselfluid_amd import SPHEngine, scenes
+    n3 = 8
+    p, pos = scenes.reference_scene(n3)
+    p.math_mode = EXACT
+    rng = np.random.default_rng(5)
+    pos = (pos + (rng.random(pos.shape, dtype=np.float32) - np.float32(0.5)) * np.float32(0.2)).astype(np.float32)
+    bpos = _box_vertices(1.25, 0.25)
+    p.capacity = n3 ** 3 + bpos.shape[0]
+    eng = SPHEngine(p, device=0)
+    eng.upload("positions", pos[::-1].copy())  # (an order the sort has to change)
+    eng.density_all()
+    rho0 = eng.download("densities")
+    assert rho0.min() > 0 and np.unique(rho0).size > 100
+    eng.add_boundary_particles(bpos)          # densities are stale now ...
+    eng.nn()                                  # ... and the sort re-orders every array
+    assert np.array_equal(eng.download("densities"), rho0)
+    q = eng.params
+    q.mass = 2.0 * q.mass
+    eng.set_params(q)                         # stale again (rho scales with the mass), still on their particles
+    eng.nn()
+    assert np.array_equal(eng.download("densities"), rho0)
+    eng.density_all()
+    assert not np.array_equal(eng.download("densities"), rho0)
+    eng.close()
+
+
+def test_set_params_wants_the_current_boundary_count():
+    """dsl_set_params with the creation-time block after dsl_add_boundary_particles used to leave
+    dsl_get_params reporting n_boundary = 0; now it is refused, and the refreshed block is accepted."""
+    from dieselfluid_amd import SPHEngine, scenes
+    from dieselfluid_amd._lib import DslError
+    n3 = 8
+    p, pos = scenes.reference_scene(n3)
+    bpos = _box_vertices(1.25, 0.5)
+    p.capacity = n3 ** 3 + bpos.shape[0]
+    eng = SPHEngine(p, device=0)
+    eng.upload("positions", pos)
+    eng.add_boundary_particles(bpos)
+    with pytest.raises(DslError):
+        eng.set_params(p)                     # p.n_boundary is still 0
+    q = eng.params
+    assert q.n_boundary == bpos.shape[0]
+    q.mu = 2.0 * q.mu
+    eng.set_params(q)
+    assert eng.params.n_boundary == bpos.shape[0] and eng.n_fluid == n3 ** 3
+    eng.close()

@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import helpers
+from oracle import pyoracle as po
 from test_slab_cpu import _free_port, _vel_fn
 
 pytestmark = pytest.mark.gpu
@@ -18,7 +19,7 @@ pytestmark = pytest.mark.gpu
 STEPS = 10
 
 
-def _worker(rank, world, port, math_mode, n3, overlap, vscale, out, axis=2):
+def _worker(rank, world, port, math_mode, n3, overlap, vscale, out, axis=2, native=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -28,18 +29,25 @@ def _worker(rank, world, port, math_mode, n3, overlap, vscale, out, axis=2):
     torch.cuda.set_device(0)
     from dieselfluid_amd.slab import SlabDriver
     SlabDriver.REPLAN_EVERY = 4  # exercise the message re-sizing inside the run
-    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=axis, overlap=overlap,
+    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=axis, overlap=overlap, native=native,
                               vel_fn=lambda ids, pos: vscale * _vel_fn(ids, pos, axis=axis))
     assert drv.overlap == (overlap if overlap is not None else math_mode == 1)
+    assert bool(getattr(drv, "native", False)) == native
     caps0 = (drv.engine.cap_full, drv.engine.cap_x)
     drv.wcsph_step(STEPS)
     res = drv.gather_state(n3 ** 3)
     st = drv.engine.status()
     info = [None] * world if rank == 0 else None
     dist.gather_object((drv.engine.n, drv.engine_core.n_owned(), st[0], st[1], caps0[0], drv.engine.cap_full), info, dst=0)
+    calls = [None] * world if rank == 0 else None
+    dist.gather_object(list(drv.engine_core._comm.calls) if native else [], calls, dst=0)
     if rank == 0:
         gp, gv, seen = res
         np.savez(out, pos=gp, vel=gv, seen=seen, info=np.array(info))
+        if native:
+            import pickle
+            with open(out + ".calls", "wb") as f:
+                pickle.dump(calls, f)
     dist.destroy_process_group()
 
 
@@ -60,6 +68,38 @@ def _single(n3, math_mode, vscale, steps=STEPS, shuffle=False, axis=2):
     eng.wcsph_step(steps)
     inv = np.argsort(perm)
     return eng.download("positions")[inv], eng.download("velocities")[inv]
+
+
+def _bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32),
+                          np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def _oracle_single(n3, vscale, steps=STEPS, axis=2, pcisph=False, params_hook=None):
+    """the same scene on the CPU oracle, single domain, EXACT arithmetic in the reference's order"""
+    from dieselfluid_amd import scenes
+    p, pos = scenes.dambreak_scene(n3, math_mode=0)
+    if params_hook is not None:
+        params_hook(p)
+    vel = (vscale * _vel_fn(np.arange(n3 ** 3), pos, axis)).astype(np.float32)
+    frc = np.tile(np.array(p.force_reset[:], np.float32), (n3 ** 3, 1))
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel, force=frc)
+    if pcisph:
+        ora.delta = p.delta
+        ora.pcisph_begin()
+        ora.pcisph_step(steps)
+    else:
+        ora.wcsph_step(steps)
+    return ora.positions(), ora.velocities()
+
+
+def _assert_identical(what, got_pos, got_vel, pos, vel):
+    """DSL_MATH_EXACT: cells are ascending in (global) particle id, slab planes and every rank's grid origin lie on
+    cell planes of the single-domain grid, ghost densities come from a complete 2h band -- every sum of every owned
+    particle has the same terms in the same order as in the single-domain run, so the states are the same BITS."""
+    nx = int(np.count_nonzero(np.ascontiguousarray(got_pos, np.float32).view(np.uint32) != pos.view(np.uint32)))
+    nv = int(np.count_nonzero(np.ascontiguousarray(got_vel, np.float32).view(np.uint32) != vel.view(np.uint32)))
+    assert nx == 0 and nv == 0, f"EXACT slabs differ from {what}: {nx} position words, {nv} velocity words"
 
 
 @pytest.mark.parametrize("math_mode,overlap,world,n3", [
@@ -83,11 +123,17 @@ def test_hip_slabs_match_single_engine(tmp_path, math_mode, overlap, world, n3):
     assert np.all(info[:, 3] == 0)          # split step: the margin held
     assert np.all(info[:, 5] != info[:, 4])  # messages were re-sized to the band occupancy
     pos, vel = _single(n3, math_mode, 1.0)
-    # The two counter-streaming particle populations of this scene amplify float32 summation-order
-    # noise quickly; the yardstick is what re-ordering the particles and moving the grid origin does to
-    # a single-engine run.  Slabs (own order and own grid per rank) must stay within a small multiple.
+    if math_mode == 0:
+        # EXACT: identical, not close -- to the single engine and to the single-domain oracle
+        _assert_identical("the single engine", z["pos"], z["vel"], pos, vel)
+        opos, ovel = _oracle_single(n3, 1.0)
+        _assert_identical("the single-domain oracle", z["pos"], z["vel"], opos, ovel)
+        return
+    # FAST: tile-relative coordinates round differently on a rank's own grid.  The two counter-streaming
+    # particle populations of this scene amplify float32 rounding noise quickly; the yardstick is what
+    # re-ordering the particles and moving the grid origin does to a single-engine run.  Slabs (own order
+    # and own grid per rank) must stay within a small multiple.
     pos_s, vel_s = _single(n3, math_mode, 1.0, shuffle=True)
-    # (the order inside a cell comes from atomics, so even that yardstick varies a little from run to run)
     tol_x = max(4e-6, 5.0 * helpers.rel_err(pos_s, pos))
     tol_v = max(1e-4, 5.0 * helpers.rel_err(vel_s, vel))
     ex, ev = helpers.rel_err(z["pos"], pos), helpers.rel_err(z["vel"], vel)
@@ -159,7 +205,7 @@ def _pci_params(p, extra):
         p.st_kappa = 25.0 * p.h * p.h
 
 
-def _pci_worker(rank, world, port, math_mode, n3, extra, out):
+def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -168,7 +214,7 @@ def _pci_worker(rank, world, port, math_mode, n3, extra, out):
     import torch
     torch.cuda.set_device(0)
     from dieselfluid_amd.slab import SlabDriver
-    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=2, pcisph=True,
+    drv = SlabDriver.dambreak(n3, math_mode=math_mode, device=0, axis=2, pcisph=True, native=native,
                               params_hook=lambda p: _pci_params(p, extra),
                               vel_fn=lambda ids, pos: 0.5 * _vel_fn(ids, pos, axis=2))
     assert drv.engine.eng.slab_record_floats() == 13
@@ -178,9 +224,15 @@ def _pci_worker(rank, world, port, math_mode, n3, extra, out):
     stats = drv.engine_core.stats()
     info = [None] * world if rank == 0 else None
     dist.gather_object((drv.engine_core.n_owned(), st[0], stats.pci_iters, stats.pci_max_error), info, dst=0)
+    calls = [None] * world if rank == 0 else None
+    dist.gather_object(list(drv.engine_core._comm.calls) if native else [], calls, dst=0)
     if rank == 0:
         gp, gv, seen = res
         np.savez(out, pos=gp, vel=gv, seen=seen, info=np.array(info, dtype=np.float64))
+        if native:
+            import pickle
+            with open(out + ".calls", "wb") as f:
+                pickle.dump(calls, f)
     dist.destroy_process_group()
 
 
@@ -204,7 +256,8 @@ def _pci_single(n3, math_mode, extra, shuffle=False):
     return eng.download("positions")[inv], eng.download("velocities")[inv], st.pci_iters, st.pci_max_error
 
 
-@pytest.mark.parametrize("math_mode,world,n3,extra", [(0, 2, 16, False), (1, 2, 16, True), (1, 3, 24, True)])
+@pytest.mark.parametrize("math_mode,world,n3,extra", [(0, 2, 16, False), (0, 3, 24, False), (0, 3, 24, True),
+                                                      (1, 2, 16, True), (1, 3, 24, True)])
 def test_pcisph_slabs_match_single_engine(tmp_path, math_mode, world, n3, extra):
     out = str(tmp_path / "slab_pci.npz")
     mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out), nprocs=world, join=True)
@@ -217,6 +270,13 @@ def test_pcisph_slabs_match_single_engine(tmp_path, math_mode, world, n3, extra)
     assert np.allclose(info[:, 3], info[0, 3], rtol=0, atol=0)  # ... on the same, global, error
     pos, vel, iters, err = _pci_single(n3, math_mode, extra)
     assert int(info[0, 2]) == iters
+    if math_mode == 0:
+        # EXACT: the same bits as the single engine (error word included) and as the single-domain oracle
+        assert np.float32(info[0, 3]) == np.float32(err)
+        _assert_identical("the single engine", z["pos"], z["vel"], pos, vel)
+        opos, ovel = _oracle_single(n3, 0.5, pcisph=True, params_hook=lambda p: _pci_params(p, extra))
+        _assert_identical("the single-domain oracle", z["pos"], z["vel"], opos, ovel)
+        return
     assert abs(info[0, 3] - err) <= 1e-3 * max(err, 1e-6)
     pos_s, vel_s, _, _ = _pci_single(n3, math_mode, extra, shuffle=True)
     tol_x = max(4e-6, 5.0 * helpers.rel_err(pos_s, pos))
@@ -225,6 +285,77 @@ def test_pcisph_slabs_match_single_engine(tmp_path, math_mode, world, n3, extra)
     print(f"pcisph slab-vs-single x {ex:.2e} (tol {tol_x:.2e})  v {ev:.2e} (tol {tol_v:.2e})  iters {iters} err {err:.3e}")
     assert ex < tol_x
     assert ev < tol_v
+
+
+def _load_calls(out):
+    import pickle
+    with open(out + ".calls", "rb") as f:
+        return pickle.load(f)
+
+
+def _check_exchange_calls(calls, world):
+    """what the library asked of the transport, rank by rank: every exchange is one group of a send and a recv per
+    neighbour (sends first, then the receives in lo, hi order), a middle rank talks to two DISTINCT peers, and the
+    re-plan's 4-word all-reduce happened on every rank"""
+    for rank, seq in enumerate(calls):
+        nbs = [r for r in (rank - 1, rank + 1) if 0 <= r < world]
+        groups, cur = [], None
+        for c in seq:
+            if c == "group_start":
+                cur = []
+            elif c == "group_end":
+                groups.append(cur)
+                cur = None
+            elif isinstance(c, tuple) and c[0] in ("send", "recv"):
+                assert cur is not None, "a transfer outside a group"
+                cur.append(c)
+        assert len(groups) >= STEPS
+        for g in groups:
+            assert [c[0] for c in g] == ["send"] * len(nbs) + ["recv"] * len(nbs)
+            assert [c[1] for c in g] == nbs + nbs
+            assert len({c[2] for c in g}) == 1  # one message size per exchange, the same in both directions
+        assert ("all_reduce_max", 4) in seq
+
+
+@pytest.mark.parametrize("math_mode,overlap,world,n3", [
+    (0, None, 2, 16),    # EXACT, unsplit
+    (1, True, 2, 32),    # split step, interior tiles
+    (1, False, 3, 24),   # a middle rank: two distinct peers
+    (1, True, 3, 24),
+])
+def test_native_step_driver_between_distinct_ranks(tmp_path, math_mode, overlap, world, n3):
+    """the library's own step driver (dsl_slab_wcsph_step: group send/recv, split step,
+    re-plan all-reduce) between 2 and 3 DISTINCT ranks.  RCCL refuses several ranks on one device, so the
+    communicator is a dsl_comm_create_custom one whose table stages the messages through the host and gloo
+    (engine.HostStagedComm) -- the library makes the same call sequence as to RCCL.  Bit for bit the Python
+    protocol's result, in both math modes."""
+    out_py, out_nat = str(tmp_path / "py.npz"), str(tmp_path / "native.npz")
+    mp.spawn(_worker, args=(world, _free_port(), math_mode, n3, overlap, 1.0, out_py), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), math_mode, n3, overlap, 1.0, out_nat, 2, True), nprocs=world, join=True)
+    a, b = np.load(out_py), np.load(out_nat)
+    assert np.all(b["seen"] == 1)
+    assert b["info"][:, 1].sum() == n3 ** 3
+    assert np.all(b["info"][:, 2] == 0) and np.all(b["info"][:, 3] == 0)
+    assert _bits_equal(a["pos"], b["pos"]) and _bits_equal(a["vel"], b["vel"])
+    _check_exchange_calls(_load_calls(out_nat), world)
+
+
+@pytest.mark.parametrize("math_mode,world,n3,extra", [(0, 2, 16, False), (1, 3, 24, True)])
+def test_native_pcisph_driver_between_distinct_ranks(tmp_path, math_mode, world, n3, extra):
+    """dsl_slab_pcisph_step between distinct ranks: one exchange per step plus one 1-word MAX all-reduce of the
+    iteration error per correction iteration, on every rank; same bits as the Python protocol."""
+    out_py, out_nat = str(tmp_path / "py.npz"), str(tmp_path / "native.npz")
+    mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out_py), nprocs=world, join=True)
+    mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out_nat, True), nprocs=world, join=True)
+    a, b = np.load(out_py), np.load(out_nat)
+    assert np.all(b["seen"] == 1)
+    assert np.array_equal(a["info"], b["info"])  # owned counts, status, iteration count, error: identical
+    assert _bits_equal(a["pos"], b["pos"]) and _bits_equal(a["vel"], b["vel"])
+    calls = _load_calls(out_nat)
+    for seq in calls:
+        n_red = sum(1 for c in seq if c == ("all_reduce_max", 1))
+        assert n_red == STEPS * 4, n_red  # pci_max_iters = 4: the reduce runs in every iteration, converged or not
+        assert ("all_reduce_max", 4) in seq
 
 
 def test_native_step_driver_matches_the_python_protocol():
