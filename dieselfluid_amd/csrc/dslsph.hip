@@ -406,7 +406,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   h->grid_valid = true;
   if (!h->lsh) {
     rc = timed(h, DSL_K_TILE_LIST, [&] {
-      hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.ntiles)), dim3(kBlock), 0, h->stream, h->c, h->tg,
+      hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, h->c, h->tg,
                          h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr, h->tile_desc_of,
                          h->unordered, h->ncell_pad / 32);
       // the tables of the non-empty tiles, once per build for every kernel that sweeps tiles
@@ -876,6 +876,21 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
+  {  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
+    int bx = 8, by = 4, bz = 4;
+    if (const char* e = std::getenv("DSL_TILE_BOX")) {  // "bx,by,bz" (A/B runs); "0" = the tile grid's linear order
+      bx = by = bz = 0;
+      if (std::sscanf(e, "%d,%d,%d", &bx, &by, &bz) < 3 || bx <= 0 || by <= 0 || bz <= 0) bx = by = bz = 0;
+    }
+    h->tg.bx = bx;
+    h->tg.by = by;
+    h->tg.bz = bz;
+    h->tg.nbx = bx ? (h->tg.tnx + bx - 1) / bx : 0;
+    h->tg.nby = bx ? (h->tg.tny + by - 1) / by : 0;
+    const long long nlist = bx ? (long long)h->tg.nbx * h->tg.nby * ((h->tg.tnz + bz - 1) / bz) * (bx * by * bz) : h->tg.ntiles;
+    if (nlist > 0x7fffffffLL) return bail(fail(h, DSL_ERR_INVALID, "tile grid too large"));
+    h->tg.nlist = (int)nlist;
+  }
   if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
   // a non-empty tile holds a particle: at most min(tiles, capacity) tables (1.5 KB each)
   if ((rc = dev_alloc(h, &h->tile_desc_of, (size_t)kTileLists * h->tg.ntiles)) ||

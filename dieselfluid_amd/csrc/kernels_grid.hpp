@@ -335,7 +335,11 @@ __global__ __launch_bounds__(kBlock) void k_pack1(int n, float* __restrict__ sta
 // ---------------------------------------------------------------------------------
 constexpr int kRecord = 7;      // full record: x,y,z,vx,vy,vz,id-bits
 constexpr int kRecordPci = 13;  // ... + the PCISPH predictor state (_pos, _vel) once dsl_pcisph_begin has run
-constexpr int kRecordX = 3;     // position-only record: x,y,z
+// position-only record: x,y,z,id-bits.  (The id used to stay behind, 12 bytes per record: the receiver numbered these
+// ghosts itself, so inside a cell they sat in message order instead of id order -- the densities of the ghosts next
+// to them were then summed in another order than a single-domain run sums them, and EXACT slabs were one ulp away
+// from it in a few particles per step.  With the id every cell of every rank is in the single-domain order.)
+constexpr int kRecordX = 4;
 
 // Message layout (floats): header of `rec` words ([0] = full-record count, [1] =
 // position-only count, int bits), cap_full full records of `rec` words (rec = kRecord or
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_write(DevConsts c, SlabBands sb
           r[0] = px[i];
           r[1] = py[i];
           r[2] = pz[i];
+          r[3] = __int_as_float(ids[i]);
         }
       }
       at += __builtin_popcountll(bal[k][it]);
@@ -554,7 +559,7 @@ __device__ __forceinline__ void slab_counts(const float* msg, int cap_full, int 
 }
 
 // appends the records of up to two messages behind the current particles: per message the full
-// records first, then the position-only ones (velocity 0, a negative id: they are ghosts by construction).
+// records first, then the position-only ones (velocity 0; ghosts by construction: beyond width_full of the plane).
 // blockIdx.y selects the message; the second one lands behind the first.
 __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict__ msg0,
                                                         const float* __restrict__ msg1, int cap_full, int cap_x,
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_append(const float* __restrict_
     vx[d] = 0.f;
     vy[d] = 0.f;
     vz[d] = 0.f;
-    ids[d] = -2 - (int)(blockIdx.y * cap_x + j);  // negative = position-only ghost; distinct: the sort orders a cell by id
+    ids[d] = __float_as_int(r[3]);  // the global id: cells are ordered by id on every rank as in a single-domain run
     if (rec == kRecordPci) {  // ghosts: never predicted, any finite value will do
       pcip.x[d] = r[0] + shx;
       pcip.y[d] = r[1] + shy;

@@ -43,25 +43,48 @@ constexpr int kMaskWords = 19;
 constexpr int kMaskValid = 9, kMaskHigh = 10;
 
 struct TileMeta {
+  // per interior row ir = 0..15 (ONE ds_read_b128 per target): .x = global slot of the row's target 0 minus the row's
+  // first target index, .y = the same for its LDS record, .z = the target indices at which tile-local x cells 2 and 3
+  // begin (16 bits each), .w = where cell 4 begins
+  int4 trow[kTB * kTB];
   int row_gs[kTRows];        // first global slot of the staged row
   int row_len[kTRows];       // particles in the row
   int row_lds[kTRows + 1];   // first LDS record of the row (rows are kTPad apart)
-  int cellS[kTRows * (kTH + 1)];  // per row: offset of each of its 6 cells (+ end) inside the row
+  // the x-run of a target in tile-local x cell lx = 1..4 on staged row r: LDS records [first, end) of the row's
+  // cells lx-1 .. lx+1, packed first | end << 16 (one ds_read_b32 where the sweeps used to read three table
+  // entries and add them up, 9 times per target and kernel)
+  int run[kTRows * kTB];
   int tprefix[kTB * kTB + 1];     // prefix of target counts over the 16 interior rows
   int overflow;
   int tile;                       // the tile's id in the tile grid
-  int pad_[4];                    // 384 ints: a whole number of 16-byte pieces
+  int centre[3];                  // float bits: the tile centre in world coordinates (origin of the tile-relative records)
+  int pad_;                       // 340 ints: a whole number of 16-byte pieces
 };
 // A tile's table is built ONCE per neighbour build, by k_tile_desc, into a global array of these
 // (one per non-empty tile, in the order of tile list 0); the sweeping kernels copy it into LDS, one
 // dword per lane, one tile ahead of its use.  (Each kernel used to derive it again for every tile it
 // visited -- seven dependent loads per row, a scan and two more barriers in front of every staging.)
-constexpr int kMetaInts = 384;
+constexpr int kMetaInts = 340;
 static_assert(sizeof(TileMeta) == kMetaInts * sizeof(int), "TileMeta is copied as kMetaInts dwords");
 
 struct TileGrid {
   int tnx, tny, tnz, ntiles;
+  // Enumeration order of the tile list (k_tile_list): boxes of bx x by x bz tiles, the boxes x-fastest and the
+  // tiles of a box x-fastest -- NOT the tile grid's own linear order.  The persistent kernels deal the list to
+  // the 8 XCDs in groups of 128 consecutive entries (TileWalk), so with 128-tile boxes every XCD works on one
+  // compact 3-D box of tiles at a time and the halo rows its tiles share are served by that XCD's L2: the
+  // tiles of a box fetch 1.3 x its particles from HBM, where 128 tiles of the linear order (a 32 x 4 x 1 sheet)
+  // fetch 1.7 x and share nothing with the sheets above and below.  bx = 0: linear order.
+  int bx, by, bz, nbx, nby, nlist;  // nlist = list threads = boxes * box size
 };
+__device__ __forceinline__ int tile_of_list_thread(const TileGrid& tg, int t) {
+  if (tg.bx == 0) return t < tg.ntiles ? t : -1;
+  const int per = tg.bx * tg.by * tg.bz;
+  const int box = t / per, w = t - box * per;
+  const int ox = box % tg.nbx, oy = (box / tg.nbx) % tg.nby, oz = box / (tg.nbx * tg.nby);
+  const int tx = ox * tg.bx + w % tg.bx, ty = oy * tg.by + (w / tg.bx) % tg.by, tz = oz * tg.bz + w / (tg.bx * tg.by);
+  return (tx < tg.tnx && ty < tg.tny && tz < tg.tnz) ? tx + tg.tnx * (ty + tg.tny * tz) : -1;
+}
 
 #ifdef DSL_DIAG_STAMPS  // diagnostic build only: per-phase clocks of wave 0 of every block (s_memtime)
 __device__ unsigned long long g_diag[32];
@@ -88,20 +111,21 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
                                                       int* __restrict__ short_pass_tiles, int* __restrict__ n_live,
                                                       int* __restrict__ desc_of, unsigned int* __restrict__ unordered,
                                                       int unordered_words) {
-  const int t = blockIdx.x * kBlock + threadIdx.x;
+  const int lt = blockIdx.x * kBlock + threadIdx.x;  // list thread: tiles are enumerated box by box (TileGrid)
   // the sort's "cells to order" bitmap (kernels_grid.hpp) has been consumed: clean for the next build
   // (64 cells per tile = two words per tile thread; saves the build a memset launch)
   if (unordered != nullptr) {
-    if (2 * t < unordered_words) unordered[2 * t] = 0u;
-    if (2 * t + 1 < unordered_words) unordered[2 * t + 1] = 0u;
+    if (2 * lt < unordered_words) unordered[2 * lt] = 0u;
+    if (2 * lt + 1 < unordered_words) unordered[2 * lt + 1] = 0u;
   }
   // slab mode: the sort has dropped the stale ghosts; the live count (kept on the device) is the
   // start of the pseudo cell behind the last one.  Nothing in this launch reads the count.
-  if (t == 0 && n_live) *n_live = cell_start[c.ncell];
+  if (lt == 0 && n_live) *n_live = cell_start[c.ncell];
   const int lane = threadIdx.x & (kWave - 1);
+  const int t = tile_of_list_thread(tg, lt);
   int cnt = 0;
   bool in_band = false, in_inner = false, owning = false, ghosts = false;
-  if (t < tg.ntiles) {
+  if (t >= 0) {
     const int tx = t % tg.tnx, ty = (t / tg.tnx) % tg.tny, tz = t / (tg.tnx * tg.tny);
     const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
     const int xa = tx * kTB, xb = min(xa + kTB, nx);
@@ -215,15 +239,27 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
     if (row) {
       out->row_gs[lane] = r.s[0];
       out->row_len[lane] = len;
-      out->row_lds[lane] = inc - v;
+      const int lds0 = inc - v;
+      out->row_lds[lane] = lds0;
 #pragma unroll
-      for (int k = 0; k <= kTH; ++k) out->cellS[lane * (kTH + 1) + k] = r.s[k] - r.s[0];
-      if (interior) out->tprefix[(rz - 1) * kTB + (ry - 1)] = tinc - tv;
+      for (int lx = 1; lx <= kTB; ++lx)
+        out->run[lane * kTB + lx - 1] = (lds0 + (r.s[lx - 1] - r.s[0])) | ((lds0 + (r.s[lx + 2] - r.s[0])) << 16);
+      if (interior) {
+        const int ir = (rz - 1) * kTB + (ry - 1), t0 = tinc - tv;  // the row's first target
+        out->tprefix[ir] = t0;
+        out->trow[ir] = make_int4(r.s[1] - t0, lds0 + (r.s[1] - r.s[0]) - t0,
+                                  (t0 + (r.s[2] - r.s[1])) | ((t0 + (r.s[3] - r.s[1])) << 16), t0 + (r.s[4] - r.s[1]));
+      }
       if (lane == kTRows - 1) {  // (the last interior row is lane 28: this lane's inclusive sums are the totals)
         out->row_lds[kTRows] = inc;
+        // (a tile that overflows the LDS budget is never staged: its packed run bounds may be garbage.  Target
+        // indices fit 16 bits as long as the staged records do -- the targets are among them)
         out->overflow = inc > kTCap ? 1 : 0;
         out->tprefix[kTB * kTB] = tinc;
         out->tile = tile;
+        out->centre[0] = __float_as_int(c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h);
+        out->centre[1] = __float_as_int(c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h);
+        out->centre[2] = __float_as_int(c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h);
       }
     }
   };
@@ -250,23 +286,31 @@ __device__ __forceinline__ void tile_meta_store(TileMeta& m, int word) {
   if (tid < kMetaInts) reinterpret_cast<int*>(&m)[tid] = word;
 }
 
-// target index inside the tile -> interior row id (0..15), staged row, offset inside the row
-__device__ __forceinline__ void tile_target(const TileMeta& m, int t, int& srow, int& off) {
+// target index inside the tile -> its staged row, global slot, LDS record and tile-local x cell (1..4): the cell is
+// read off the row's cell table, i.e. exactly the cell the sort put the particle in (no second evaluation of the
+// cell rule, no load of the position)
+struct TileTarget {
+  int srow, g, own, lx;
+};
+__device__ __forceinline__ TileTarget tile_target(const TileMeta& m, int t) {
   int ir = 0;  // largest interior row with tprefix[ir] <= t: binary search over the 16 rows
   ir += (t >= m.tprefix[ir + 8]) ? 8 : 0;
   ir += (t >= m.tprefix[ir + 4]) ? 4 : 0;
   ir += (t >= m.tprefix[ir + 2]) ? 2 : 0;
   ir += (t >= m.tprefix[ir + 1]) ? 1 : 0;
-  srow = (ir / kTB + 1) * kTH + (ir % kTB + 1);
-  off = m.cellS[srow * (kTH + 1) + 1] + (t - m.tprefix[ir]);
+  const int4 w = m.trow[ir];
+  TileTarget r;
+  r.srow = (ir / kTB + 1) * kTH + (ir % kTB + 1);
+  r.g = w.x + t;
+  r.own = w.y + t;
+  r.lx = 1 + ((t >= (w.z & 0xffff)) ? 1 : 0) + ((t >= (int)((unsigned)w.z >> 16)) ? 1 : 0) + ((t >= w.w) ? 1 : 0);
+  return r;
 }
-
-// tile-local x cell (1..4) of the target at offset `off` of staged row `srow`: read off the row's
-// cell table, i.e. exactly the cell the sort put the particle in (no second evaluation of the
-// cell rule, no load of the position)
-__device__ __forceinline__ int tile_target_cell(const TileMeta& m, int srow, int off) {
-  const int* cs = &m.cellS[srow * (kTH + 1)];
-  return 1 + ((off >= cs[2]) ? 1 : 0) + ((off >= cs[3]) ? 1 : 0) + ((off >= cs[4]) ? 1 : 0);
+// the LDS record range [j, je) of the x-run around tile-local x cell lx on staged row rr
+__device__ __forceinline__ void tile_run(const TileMeta& m, int rr, int lx, int& j, int& je) {
+  const unsigned int w = (unsigned int)m.run[rr * kTB + lx - 1];
+  j = (int)(w & 0xffffu);
+  je = (int)(w >> 16);
 }
 
 // ds_read_b128 serves a wave in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and
@@ -498,12 +542,18 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
                                                           const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
                                                           float* __restrict__ rho, float* __restrict__ pterm,
                                                           unsigned int* __restrict__ nmask, int mstride) {
-  // The NEXT tile's table (k_tile_desc) travels, one dword per lane, under the current tile's staging and is
-  // put into the other LDS copy behind it: a tile starts with ONE barrier and its table in place.
-  // (Carrying the next tile's records through the sweep as well -- 12 registers per lane -- bought nothing
-  // once the staging was down to three loads per lane: 0.794 ms with, 0.780 without, at 16M particles.)
-  __shared__ TileMeta metas[2];
-  __shared__ float4 A[kTCap];
+  // FAST: the LDS image is DOUBLE-BUFFERED (r03).  A tile's life used to be barrier, staging (load issue, one exposed
+  // memory round trip, LDS writes), barrier, sweep: per-phase clocks put the sweep at 57 % of it, and with two
+  // workgroups per CU a quarter of the time NEITHER was sweeping (profiles/r03_*).  Now the loads of tile k+1 are
+  // issued right behind the barrier that starts the sweep of tile k (12 registers per lane carry them through it),
+  // every wave commits them to the OTHER image as soon as ITS OWN sweep is over -- no barrier in between: that image
+  // was last read by the sweep of tile k-1, which every wave had left before this tile's barrier -- and the table of
+  // tile k+2 rotates through a third copy the same way.  One barrier per tile, no exposed round trip.
+  // 2 x 36.9 KB + 3 tables = 78 KB per workgroup: two workgroups still fit a CU's 160 KB.
+  // EXACT keeps one image (its second array holds the pre-filter's tile-relative records) and the old order.
+  constexpr bool DB = !EXACT;
+  __shared__ TileMeta metas[DB ? 3 : 2];
+  __shared__ float4 Abuf[DB ? 2 : 1][kTCap];
   // EXACT: A holds the raw coordinates the exact walk needs, R the tile-relative records of the FAST test, which
   // the candidate sweep uses as a conservative pre-filter (see below)
   __shared__ float4 R[EXACT ? kTCap : 1];
@@ -512,56 +562,37 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   // (n_tiles is the base of the tile-list counters here; a slab always has half-empty ghost tiles: the host
   // launches the pass-sharing instantiation alone)
   if (!EXACT && c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
-  TileFeed feed(desc_of, *n_tiles);
-  int di = 0;
-  bool have = feed.pop(di);
-  if (have) tile_meta_store(metas[0], tile_meta_request(desc, di));
-  for (int cur = 0; have; cur ^= 1) {
-    TileMeta& m = metas[cur];
-    DSL_STAMP(d0);
-    __syncthreads();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
-    DSL_STAMP(d1);
-    DSL_STAMP_ADD(4, d0, d1);
-    have = feed.pop(di);
-    int table_word = 0;
-    if (have) table_word = tile_meta_request(desc, di);
-    const bool ovf = m.overflow != 0;
-    // tile centre in world coordinates
-    const int tile = m.tile;
-    const float ox = c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h;
-    const float oy = c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h;
-    const float oz = c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h;
-    if (!ovf) {
-      stage_rows<3>(
-          m,
-          [&](int g, float4* o) {
-            o[0] = load4u(p.x + g);
-            o[1] = load4u(p.y + g);
-            o[2] = load4u(p.z + g);
-          },
-          [&](int g, float* o) {
-            o[0] = p.x[g];
-            o[1] = p.y[g];
-            o[2] = p.z[g];
-          },
-          [&](int slot, const float* o, bool real) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
-            if (real) {
-              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
-              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-            }
-            if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
-              A[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
-              R[slot] = v;
-            } else {
-              A[slot] = v;
-            }
-          });
-    }
-    if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
-    __syncthreads();
+  auto load4 = [&](int g, float4* o) {
+    o[0] = load4u(p.x + g);
+    o[1] = load4u(p.y + g);
+    o[2] = load4u(p.z + g);
+  };
+  auto load1 = [&](int g, float* o) {
+    o[0] = p.x[g];
+    o[1] = p.y[g];
+    o[2] = p.z[g];
+  };
+  // registers -> records of image `img`, relative to the centre of the tile `mt` describes
+  auto commit = [&](const TileMeta& mt, const StageRegs<3>& sr, float4* img) {
+    const float ox = __int_as_float(mt.centre[0]), oy = __int_as_float(mt.centre[1]), oz = __int_as_float(mt.centre[2]);
+    stage_commit<3>(mt, sr, load1, [&](int slot, const float* o, bool real) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+      if (real) {
+        const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+        v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+      }
+      if constexpr (EXACT) {  // raw coordinates; a pad is far away from everything
+        img[slot] = real ? make_float4(o[0], o[1], o[2], 0.0f) : make_float4(kFar, kFar, kFar, 0.0f);
+        R[slot] = v;
+      } else {
+        img[slot] = v;
+      }
+    });
+  };
+  // the sweep of one staged tile: table m, image A
+  auto sweep = [&](const TileMeta& m, const float4* __restrict__ A) {
     DSL_STAMP(d2);
-    DSL_STAMP_ADD(5, d1, d2);
+    const bool ovf = m.overflow != 0;
     const int ntarg = m.tprefix[kTB * kTB];
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     // Targets are taken kTBlock at a time, one lane each.  A tile's LDS slot is held for as long as
@@ -570,16 +601,14 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     // target, each sweeping every k-th of the 9 runs, sums combined by shuffles (for_each_target).
     for_each_target<SHARE>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;
-      int srow, off;
-      tile_target(m, t, srow, off);
-      const int g = m.row_gs[srow] + off;
+      const TileTarget tt = tile_target(m, t);
+      const int srow = tt.srow, g = tt.g, lx = tt.lx;
       float acc = 0.0f, acc1 = 0.0f, self_term = 1.0f;
       unsigned int mvalid = 0u;
       if constexpr (EXACT) {
         if (!ovf) {
-          const int own = m.row_lds[srow] + off;
+          const int own = tt.own;
           const float4 me = A[own];
-          const int lx = tile_target_cell(m, srow, off);
           const int pad_rec = m.row_lds[1] - kTPad;
           float density = 0.0f;
           // The candidate sweep only has to find a SUPERSET of {dist < h}: the walk below forms the reference's
@@ -608,9 +637,8 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
 #pragma unroll 1
           for (int ri = 0; ri < 9; ++ri) {
             const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
-            const int rb = m.row_lds[rr];
-            int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-            const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            int j, je;
+            tile_run(m, rr, lx, j, je);
             if (je - j <= 64) mvalid |= 1u << ri;
             if (!(j < je)) nmask[(size_t)ri * mstride + g] = 0u;  // an empty run still has a (read) mask word
             // chunks of up to 32 candidates: sweep -> mask word -> walk of its set bits, first candidate first
@@ -692,18 +720,16 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
         return;
       }
       if (!ovf) {
-        const float4 me = A[m.row_lds[srow] + off];
+        const float4 me = A[tt.own];
         // a particle whose position has gone NaN (the reference produces such next to boundary particles)
         // meets nobody, itself included: q is NaN, clamped to 0, for every candidate
         self_term = (me.x == me.x && me.y == me.y && me.z == me.z) ? 1.0f : 0.0f;
         const float two_hh = 2.0f * c.inv_hh;
         const float sx = two_hh * me.x, sy = two_hh * me.y, sz = two_hh * me.z, a0 = 1.0f + me.w;
-        const int lx = tile_target_cell(m, srow, off);
         // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
         auto sweep_run = [&](int ri, int rr) {
-          const int rb = m.row_lds[rr];
-          int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-          int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+          int j, je;
+          tile_run(m, rr, lx, j, je);
           if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
           unsigned int mask = 0u;
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: the per-tile fixed cost (set-up + staging + epilogue)
@@ -787,6 +813,70 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     });
     DSL_STAMP(d3);
     DSL_STAMP_ADD(6, d2, d3);
+  };
+  TileFeed feed(desc_of, *n_tiles);
+  int di = 0;
+  bool have = feed.pop(di);
+  if (!have) return;
+  tile_meta_store(metas[0], tile_meta_request(desc, di));
+  if constexpr (DB) {
+    bool have_next = feed.pop(di);
+    int table_word = have_next ? tile_meta_request(desc, di) : 0;
+    __syncthreads();  // the first tile's table is visible
+    {                 // the first tile is staged in the open: nothing to hide it under yet
+      StageRegs<3> sr;
+      if (!metas[0].overflow) {
+        stage_issue<3>(metas[0], load4, sr);
+        commit(metas[0], sr, Abuf[0]);
+      }
+    }
+    if (have_next) tile_meta_store(metas[1], table_word);
+    int mc = 0, mn = 1, mnn = 2;  // tables of this tile, the next one, the one after
+    for (int cur = 0; have; cur ^= 1) {
+      DSL_STAMP(d0);
+      __syncthreads();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
+      DSL_STAMP(d1);
+      DSL_STAMP_ADD(4, d0, d1);
+      StageRegs<3> sr;
+      bool have_nn = false, stage_next = false;
+      table_word = 0;
+      if (have_next) {
+        stage_next = metas[mn].overflow == 0;
+        if (stage_next) stage_issue<3>(metas[mn], load4, sr);
+        have_nn = feed.pop(di);
+        if (have_nn) table_word = tile_meta_request(desc, di);
+      }
+      DSL_STAMP(d1b);
+      DSL_STAMP_ADD(12, d1, d1b);  // next tile: load issue
+      sweep(metas[mc], Abuf[cur]);
+      DSL_STAMP(d4);
+      if (stage_next) commit(metas[mn], sr, Abuf[cur ^ 1]);
+      if (have_nn) tile_meta_store(metas[mnn], table_word);
+      DSL_STAMP(d5);
+      DSL_STAMP_ADD(13, d4, d5);  // next tile: wait for its data (if it has not landed under the sweep) + LDS writes
+      have = have_next;
+      have_next = have_nn;
+      const int t = mc;
+      mc = mn;
+      mn = mnn;
+      mnn = t;
+    }
+  } else {
+    for (int cur = 0; have; cur ^= 1) {
+      TileMeta& m = metas[cur];
+      __syncthreads();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
+      have = feed.pop(di);
+      int table_word = 0;
+      if (have) table_word = tile_meta_request(desc, di);
+      if (!m.overflow) {
+        StageRegs<3> sr;
+        stage_issue<3>(m, load4, sr);
+        commit(m, sr, Abuf[0]);
+      }
+      if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
+      __syncthreads();
+      sweep(m, Abuf[0]);
+    }
   }
 }
 
@@ -856,9 +946,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     unsigned int pre_valid = 0u, pre_word = 0u;
     if (!nolds && nmask != nullptr && tperm < m.tprefix[kTB * kTB]) {
-      int srow0, off0;
-      tile_target(m, tperm, srow0, off0);
-      const int g0 = m.row_gs[srow0] + off0;
+      const int g0 = tile_target(m, tperm).g;
       pre_valid = nmask[(size_t)kMaskValid * mstride + g0];
       pre_word = nmask[(size_t)(EXACT ? 0 : 4) * mstride + g0];  // the run visited first (FAST: the centre run, whatever the lane's mirroring)
     }
@@ -932,11 +1020,8 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       constexpr bool SHARED = decltype(shared_c)::value;
       const bool live = true;
       DSL_STAMP(t3);
-      int srow = kTH + 1, off = 0, g = 0;
-      if (live) {
-        tile_target(m, t, srow, off);
-        g = m.row_gs[srow] + off;
-      }
+      const TileTarget tt = tile_target(m, t);
+      const int srow = tt.srow, g = tt.g;
       float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, fx = 0.f, fy = 0.f, fz = 0.f;
       float xsx = 0.f, xsy = 0.f, xsz = 0.f;  // XSPH sum / correction
       float gfx = 0.f, gfy = 0.f, gfz = 0.f;  // kOutPci: the gradient term, kept apart from the force
@@ -947,7 +1032,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
         // are unconditional and the rare unstaged tile overrides them, so that the compiler keeps
         // LDS and global loads apart instead of merging them into flat loads)
         {
-          const int own = nolds ? 0 : m.row_lds[srow] + off;
+          const int own = nolds ? 0 : tt.own;
           const float4 a = A[own];
           px = a.x;
           py = a.y;
@@ -999,7 +1084,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             const float ninvh = -c.inv_h;
             float lw_ = 0.f, xw_ = 0.f;
             const float ninvhh = -c.inv_hh;
-            const int lx = tile_target_cell(m, srow, off);
+            const int lx = tt.lx;
             const int pad_rec = m.row_lds[1] - kTPad;  // first pad record of staged row 0: (kFar, kFar, kFar, 0), (0, 0, 0, 0)
             // full per-pair arithmetic for candidate record j: `fetch` issues the LDS reads, `accum`
             // does the arithmetic, so that the walk below can have the NEXT records in flight while
@@ -1016,7 +1101,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               r.idx = j;
               return r;
             };
-            const int own_rec = m.row_lds[srow] + off;
+            const int own_rec = tt.own;
             // EXACT: the loop bodies of SPHField.Gradient (sph_field.go:183-199), LaplacianForce (:259-266) and
             // the build-defined sums for one candidate, operation by operation as force_sweep<false> has them;
             // the particle itself, a pad record and a candidate at dist >= h add +0
@@ -1125,11 +1210,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // `first_word`: the run's first mask word, loaded by the caller one run ahead so that its
             // global-memory latency passes under the previous run's walk
             // (the run's LDS record range [j, je) likewise comes from the caller)
-            auto run_bounds_of_row = [&](int rr, int& j, int& je) {
-              const int rb = m.row_lds[rr];
-              j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-              je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
-            };
+            auto run_bounds_of_row = [&](int rr, int& j, int& je) { tile_run(m, rr, lx, j, je); };
             auto run_bounds = [&](int ri, int& j, int& je) {
               run_bounds_of_row(srow + (ri / 3 - 1) * kTH + (ri % 3 - 1), j, je);
             };
@@ -1234,7 +1315,20 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 return mcol + (long long)(plane0 + 4) * mstride + (ms / 3 - 1) * mz + (ms % 3 - 1) * my;
               };
               int rn = run_of(0);
-              unsigned int ahead = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);  // (not behind runs_masked)
+              // The runs' first mask words are requested kMaskAhead steps ahead of their walk (the words of steps
+              // 0 .. kMaskAhead at once, then one per step): a word comes from HBM -- the masks of 16M particles are
+              // 640 MB -- and a single run's walk is over long before that round trip is.
+#ifndef DSL_FORCE_PF
+#define DSL_FORCE_PF 1
+#endif
+              constexpr int kMaskAhead = DSL_FORCE_PF;
+              unsigned int wq[9];
+#pragma unroll
+              for (int s = 0; s < 9; ++s) wq[s] = 0u;
+              wq[0] = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);  // (not behind runs_masked)
+#pragma unroll
+              for (int s = 1; s < kMaskAhead && s < 9; ++s)
+                if (runs_masked != 0u) wq[s] = *word_of(s, 0);
               int jn, jen;
               run_bounds_of_row(row_of(0), jn, jen);
               auto second_of = [&](int s, int ri, int j, int je) {
@@ -1243,11 +1337,12 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               unsigned int ahead2 = second_of(0, rn, jn, jen);
 #pragma unroll
               for (int s = 0; s < 9; ++s) {
-                const unsigned int word = ahead, word2 = ahead2;
+                const unsigned int word = wq[s], word2 = ahead2;
                 const int j = jn, je = jen, ri = rn;
+                if (s + kMaskAhead < 9)
+                  if (runs_masked != 0u) wq[s + kMaskAhead] = *word_of(s + kMaskAhead, 0);
                 if (s < 8) {
                   rn = run_of(s + 1);
-                  if (runs_masked != 0u) ahead = *word_of(s + 1, 0);
                   run_bounds_of_row(row_of(s + 1), jn, jen);
                   ahead2 = second_of(s + 1, rn, jn, jen);
                 }
@@ -1482,52 +1577,43 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
                                                               Soa3 pv, CSoa3 gterm, Soa3 frc, float* __restrict__ press,
                                                               DevStats* stats) {
   if (stats->pci_done) return;
-  __shared__ TileMeta m;
-  __shared__ float4 A[kTCap];
+  // the LDS image is double-buffered exactly as in k_density_tiled: the next tile's loads are issued behind the
+  // barrier that starts this tile's sweep, committed to the other image by every wave as soon as its own sweep is
+  // over; one barrier per tile (there were three, and the table was fetched in the open)
+  __shared__ TileMeta metas[3];
+  __shared__ float4 Abuf[2][kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   unsigned int ebits = 0u;
-  TileFeed feed(desc_of, *n_tiles);
-  int di;
-  while (feed.pop(di)) {
-    const int table_word = tile_meta_request(desc, di);
-    __syncthreads();
-    tile_meta_store(m, table_word);
-    __syncthreads();
+  auto load4 = [&](int g, float4* o) {
+    o[0] = load4u(p.x + g);
+    o[1] = load4u(p.y + g);
+    o[2] = load4u(p.z + g);
+  };
+  auto load1 = [&](int g, float* o) {
+    o[0] = p.x[g];
+    o[1] = p.y[g];
+    o[2] = p.z[g];
+  };
+  auto commit = [&](const TileMeta& mt, const StageRegs<3>& sr, float4* img) {
+    const float ox = __int_as_float(mt.centre[0]), oy = __int_as_float(mt.centre[1]), oz = __int_as_float(mt.centre[2]);
+    stage_commit<3>(mt, sr, load1, [&](int slot, const float* o, bool real) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+      if (real) {  // records as in k_density_tiled: tile-relative x, y, z and w = -|x|^2/h^2
+        const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+        v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+      }
+      img[slot] = v;
+    });
+  };
+  auto sweep = [&](const TileMeta& m, const float4* __restrict__ A) {
     const int tile = m.tile;
     const bool ovf = m.overflow != 0;
     const int tx = tile % tg.tnx, ty = (tile / tg.tnx) % tg.tny, tz = tile / (tg.tnx * tg.tny);
-    const float ox = c.gmin[0] + (tx * kTB + 0.5f * kTB) * c.h;
-    const float oy = c.gmin[1] + (ty * kTB + 0.5f * kTB) * c.h;
-    const float oz = c.gmin[2] + (tz * kTB + 0.5f * kTB) * c.h;
-    if (!ovf) {
-      stage_rows<3>(
-          m,
-          [&](int g, float4* o) {
-            o[0] = load4u(p.x + g);
-            o[1] = load4u(p.y + g);
-            o[2] = load4u(p.z + g);
-          },
-          [&](int g, float* o) {
-            o[0] = p.x[g];
-            o[1] = p.y[g];
-            o[2] = p.z[g];
-          },
-          [&](int slot, const float* o, bool real) {
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
-            if (real) {  // records as in k_density_tiled: tile-relative x, y, z and w = -|x|^2/h^2
-              const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
-              v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
-            }
-            A[slot] = v;
-          });
-    }
-    __syncthreads();
+    const float ox = __int_as_float(m.centre[0]), oy = __int_as_float(m.centre[1]), oz = __int_as_float(m.centre[2]);
     const int ntarg = m.tprefix[kTB * kTB];
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     for (int t = tperm; t < ntarg; t += kTBlock) {
-      int srow, off;
-      tile_target(m, t, srow, off);
-      const int g = m.row_gs[srow] + off;
+      const int g = tile_target(m, t).g;
       // slab mode: a ghost's predicted density is meaningless (half a neighbourhood, no predictor
       // state) and must not decide the iteration's error
       // (a ghost is not predicted either: its predictor state travels with the particle from its owner)
@@ -1576,10 +1662,8 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
         for (int dz = -kTH; dz <= kTH; dz += kTH) {
 #pragma unroll 1
           for (int dy = -1; dy <= 1; ++dy) {
-            const int rr = qrow + dz + dy;
-            const int rb = m.row_lds[rr];
-            int j = rb + m.cellS[rr * (kTH + 1) + lx - 1];
-            const int je = rb + m.cellS[rr * (kTH + 1) + lx + 2];
+            int j, je;
+            tile_run(m, qrow + dz + dy, lx, j, je);
             for (; j + 4 < je; j += 8) {
               test4(j);
               test4(j + 4);
@@ -1604,6 +1688,45 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       press[g] += density_error * c.delta;
       const unsigned int eb = nonneg_bits(abs_err);
       ebits = eb > ebits ? eb : ebits;
+    }
+  };
+  TileFeed feed(desc_of, *n_tiles);
+  int di = 0;
+  bool have = feed.pop(di);
+  if (have) {
+    tile_meta_store(metas[0], tile_meta_request(desc, di));
+    bool have_next = feed.pop(di);
+    int table_word = have_next ? tile_meta_request(desc, di) : 0;
+    __syncthreads();  // the first tile's table is visible
+    {
+      StageRegs<3> sr;
+      if (!metas[0].overflow) {
+        stage_issue<3>(metas[0], load4, sr);
+        commit(metas[0], sr, Abuf[0]);
+      }
+    }
+    if (have_next) tile_meta_store(metas[1], table_word);
+    int mc = 0, mn = 1, mnn = 2;  // tables of this tile, the next one, the one after
+    for (int cur = 0; have; cur ^= 1) {
+      __syncthreads();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
+      StageRegs<3> sr;
+      bool have_nn = false, stage_next = false;
+      table_word = 0;
+      if (have_next) {
+        stage_next = metas[mn].overflow == 0;
+        if (stage_next) stage_issue<3>(metas[mn], load4, sr);
+        have_nn = feed.pop(di);
+        if (have_nn) table_word = tile_meta_request(desc, di);
+      }
+      sweep(metas[mc], Abuf[cur]);
+      if (stage_next) commit(metas[mn], sr, Abuf[cur ^ 1]);
+      if (have_nn) tile_meta_store(metas[mnn], table_word);
+      have = have_next;
+      have_next = have_nn;
+      const int t = mc;
+      mc = mn;
+      mn = mnn;
+      mnn = t;
     }
   }
   wave_atomic_max(&stats->pci_cur_err_bits, ebits);

@@ -6,8 +6,8 @@ transport only (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in the CPU t
 
 Per step and per neighbour ONE message: every owned particle within 2h of the slab plane.
 Those within h (and the migrants beyond the plane) travel as full records (x, v, global id:
-28 bytes; 52 with the PCISPH predictor state), the outer half of the band as positions only
-(12 bytes).  The receiver keeps full records inside its own [lo,hi) as newly owned and the
+28 bytes; 52 with the PCISPH predictor state), the outer half of the band as positions + id
+(16 bytes: the id keeps every cell in the single-domain order on every rank).  The receiver keeps full records inside its own [lo,hi) as newly owned and the
 rest as ghosts.  A 2h band lets the receiver recompute the ghosts' densities itself, so the
 force pass needs no second exchange: ghosts within h of the plane see their full
 neighbourhood, and only those contribute to owned particles.
@@ -34,7 +34,7 @@ class SlabOverflow(DslError):
     ghosts were lost, the run is no longer valid"""
 
 RECORD = 7    # full record: x,y,z,vx,vy,vz,id-bits
-RECORD_X = 3  # position-only record
+RECORD_X = 4  # position-only record: x,y,z,id-bits
 SPLIT_BAND, SPLIT_INNER = 1, 2
 
 

@@ -282,8 +282,10 @@ int dsl_download_cell_start(dsl_handle *h, int32_t *cell_start, size_t count);
  *   full    : cap_full records of 7 floats: x,y,z,vx,vy,vz and the global particle id as
  *             raw int32 bits -- every owned particle within width_full of the plane, and the
  *             migrants beyond it
- *   x-only  : cap_xonly records of 3 floats: x,y,z -- the rest of the band (out to `width`);
- *             they only feed the receiver's ghost densities
+ *   x-only  : cap_xonly records of 4 floats: x,y,z and the global id (int32 bits) -- the rest of the
+ *             band (out to `width`); they only feed the receiver's ghost densities.  The id keeps
+ *             every cell of every rank in the order of a single-domain run (ascending id), which is
+ *             what makes DSL_MATH_EXACT slabs bit-identical to it
  * Messages have a fixed size, so a step needs no host-side counts and no host
  * synchronisation: the live particle count stays on the device.  With width_full = h and
  * width = 2h the receiver recomputes the ghosts' densities itself and the force pass needs

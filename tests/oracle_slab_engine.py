@@ -8,7 +8,7 @@ import torch
 import helpers
 from oracle import pyoracle as po
 
-RECORD, RECORD_X = 7, 3
+RECORD, RECORD_X = 7, 4
 
 
 class OracleSlabEngine:
@@ -78,7 +78,9 @@ class OracleSlabEngine:
         rec = msg[RECORD:RECORD * (1 + self.cap_full)].reshape(-1, RECORD)
         rec[:nf, 0:3], rec[:nf, 3:6] = self.pos[full], self.vel[full]
         rec[:nf, 6] = self.ids[full].view(np.float32)
-        msg[RECORD * (1 + self.cap_full):].reshape(-1, RECORD_X)[:nx] = self.pos[xonly]
+        xrec = msg[RECORD * (1 + self.cap_full):].reshape(-1, RECORD_X)
+        xrec[:nx, 0:3] = self.pos[xonly]
+        xrec[:nx, 3] = self.ids[xonly].view(np.float32)
         return torch.from_numpy(msg)
 
     def pack(self, width_full, width, want_lo, want_hi):
@@ -99,10 +101,10 @@ class OracleSlabEngine:
         assert self.pos.shape[0] + nf + nx <= self.capacity
         r = m[RECORD:RECORD * (1 + self.cap_full)].reshape(-1, RECORD)[:nf]
         x = m[RECORD * (1 + self.cap_full):].reshape(-1, RECORD_X)[:nx]
-        self.pos = np.concatenate([self.pos, r[:, 0:3], x])
-        self.vel = np.concatenate([self.vel, r[:, 3:6], np.zeros_like(x)])
+        self.pos = np.concatenate([self.pos, r[:, 0:3], x[:, 0:3]])
+        self.vel = np.concatenate([self.vel, r[:, 3:6], np.zeros_like(x[:, 0:3])])
         self.ids = np.concatenate([self.ids, np.ascontiguousarray(r[:, 6]).view(np.int32),
-                                   np.full(nx, -1, np.int32)])
+                                   np.ascontiguousarray(x[:, 3]).view(np.int32)])
 
     def nn(self):
         # stale ghosts carry NaN; a particle that just crossed the plane stays one more

@@ -16,7 +16,7 @@ from test_slab_cpu import _free_port, _vel_fn
 
 pytestmark = pytest.mark.gpu
 
-STEPS = 10
+STEPS = int(os.environ.get("DSL_SLAB_TEST_STEPS", "10"))  # (the variable: tools/slab_exact_diff.py looks for the first differing step)
 
 
 def _worker(rank, world, port, math_mode, n3, overlap, vscale, out, axis=2, native=False):
