@@ -94,6 +94,10 @@ struct dsl_handle {
   bool dens_held = false;
   // the histogram / "cells to order" bitmap were handed to a build that may not have cleaned them again
   bool sort_scratch_dirty = false;
+  // exclusive prefix of the cell counts in one launch (k_scan_onepass) instead of three; DSL_SCAN_ONEPASS=0 turns it off
+  bool scan_onepass = true;
+  unsigned long long* scan_status = nullptr;  // one word per 4096-cell tile
+  unsigned long long* scan_ticket = nullptr;  // the ever-growing ticket counter
   int64_t steps = 0;
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
@@ -224,6 +228,11 @@ int dev_alloc(dsl_handle* h, T** p, size_t count) {
   // scatter up to seven keys past a cell)
   hipError_t e = hipMalloc((void**)p, count * sizeof(T) + 64);
   if (e != hipSuccess) return fail(h, DSL_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  // Every array starts from zeros (NewParticleArray zero-fills its slices too, particle_array.go:18-33): hipMalloc hands
+  // out whatever the previous owner left, and nothing a run computes may depend on that -- neither the padding the
+  // unaligned staging quads read past a row nor a plane that is only written for some particles.  Once per handle.
+  e = hipMemsetAsync(*p, 0, count * sizeof(T) + 64, h->stream);
+  if (e != hipSuccess) return fail(h, DSL_ERR_DEVICE, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
   return DSL_OK;
 }
 
@@ -341,12 +350,19 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     if (h->unordered) HIP_TRY(h, hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream));
   }
   h->sort_scratch_dirty = true;
+  const bool onepass = h->scan_onepass;
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
-                       ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered);
+                       ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
+                       onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
+    if (onepass) {  // one launch, the counts read once (kernels_grid.hpp: k_scan_onepass)
+      hipLaunchKernelGGL(k_scan_onepass, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->cell_start,
+                         h->scan_status, h->scan_ticket, h->nscan, h->dstats);
+      return;
+    }
     hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan, h->dstats,
                        !h->lsh ? h->n_tiles : nullptr);
@@ -708,6 +724,8 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->cell_count);
   (void)hipFree(h->cell_start);
   (void)hipFree(h->block_sums);
+  (void)hipFree(h->scan_status);
+  (void)hipFree(h->scan_ticket);
   (void)hipFree(h->stage);
   (void)hipFree(h->dstats);
   (void)hipFree(h->dcounter);
@@ -847,7 +865,8 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->sort_work, n)) || (rc = dev_alloc(h, &h->unordered, (size_t)h->ncell_pad / 32)) ||
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
-      (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
+      (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->scan_status, (size_t)h->nscan)) ||
+      (rc = dev_alloc(h, &h->scan_ticket, 1)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
       (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 16)) ||
       (rc = dev_alloc(h, &h->pack_counts, (size_t)4 * ((n + kPackChunk - 1) / kPackChunk))))
     return bail(rc);
@@ -876,6 +895,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
+  if (const char* e = std::getenv("DSL_SCAN_ONEPASS")) h->scan_onepass = std::atoi(e) != 0;
   {  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
     int bx = 8, by = 4, bz = 4;
     if (const char* e = std::getenv("DSL_TILE_BOX")) {  // "bx,by,bz" (A/B runs); "0" = the tile grid's linear order
@@ -2315,6 +2335,9 @@ int dsl_get_stats(dsl_handle* h, dsl_stats* out) {
   for (int a = 0; a < 3; ++a) out->grid_dims[a] = h->c.dims[a];
   out->grid_cells = h->c.ncell;
   out->max_cell_count = d.max_cell_count;
+  if (d.scan_stuck)
+    return fail(h, DSL_ERR_DEVICE, "neighbour build: the one-launch prefix scan gave up waiting for a tile (device fault?); "
+                                   "the state is void -- DSL_SCAN_ONEPASS=0 selects the three-launch scan");
   return DSL_OK;
 }
 

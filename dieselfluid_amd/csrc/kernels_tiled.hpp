@@ -466,8 +466,26 @@ __device__ __forceinline__ void stage_commit(const TileMeta& m, const StageRegs<
     store(ls + len + k, rec, false);
   }
 }
-template <int NF, class Load4, class Load1, class Store>
-__device__ __forceinline__ void stage_rows(const TileMeta& m, Load4&& load4, Load1&& load1, Store&& store) {
+// EXACT: are the first NC source arrays' staged values of this lane all acceptable to exact_div (sph_device.hpp)?
+// A row longer than the 56 records the quads cover fails (its tail never passes through these registers).
+template <int NF, int NC>
+__device__ __forceinline__ bool stage_values_ok(const TileMeta& m, const StageRegs<NF>& sr) {
+  const int t = threadIdx.x, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
+  if (r >= kTRows) return true;
+  const int len = m.row_len[r];
+  bool ok = len <= 4 * kQuadsPerRow;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (4 * k + i < len) {
+#pragma unroll
+      for (int a = 0; a < NC; ++a) ok = ok && exact_div_ok(f4_at(sr.v[a], i));
+    }
+  }
+  return ok;
+}
+// (CHECK: returns stage_values_ok of the first three source arrays, the coordinates)
+template <int NF, bool CHECK = false, class Load4, class Load1, class Store>
+__device__ __forceinline__ bool stage_rows(const TileMeta& m, Load4&& load4, Load1&& load1, Store&& store) {
   StageRegs<NF> sr;
   DSL_STAMP(s0);
   stage_issue<NF>(m, load4, sr);
@@ -476,6 +494,8 @@ __device__ __forceinline__ void stage_rows(const TileMeta& m, Load4&& load4, Loa
   stage_commit<NF>(m, sr, load1, store);
   DSL_STAMP(s2);
   DSL_STAMP_ADD(NF == 8 ? 9 : 13, s1, s2);  // staging: wait for the data + LDS writes
+  if constexpr (CHECK) return stage_values_ok<NF, 3>(m, sr);
+  return true;
 }
 
 // Which instantiation of the tiled kernels sweeps this neighbour build: the one that shares short
@@ -551,7 +571,11 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   // tile k+2 rotates through a third copy the same way.  One barrier per tile, no exposed round trip.
   // 2 x 36.9 KB + 3 tables = 78 KB per workgroup: two workgroups still fit a CU's 160 KB.
   // EXACT keeps one image (its second array holds the pre-filter's tile-relative records) and the old order.
+#ifdef DSL_DENSITY_SINGLE_BUFFER  // (A/B and diagnostic builds)
+  constexpr bool DB = false;
+#else
   constexpr bool DB = !EXACT;
+#endif
   __shared__ TileMeta metas[DB ? 3 : 2];
   __shared__ float4 Abuf[DB ? 2 : 1][kTCap];
   // EXACT: A holds the raw coordinates the exact walk needs, R the tile-relative records of the FAST test, which
@@ -572,6 +596,10 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     o[1] = p.y[g];
     o[2] = p.z[g];
   };
+  // EXACT: the walk divides with exact_div (sph_device.hpp), which equals `/` bit for bit while every staged
+  // coordinate is 0 or between 2^-20 and 2^20 in magnitude; a tile with any other value takes the global sweep
+  // (checked on the staging registers, stage_values_ok; rows longer than 56 records are not exempt: their tail is
+  // loaded record by record, so such a tile is simply taken as unsafe)
   // registers -> records of image `img`, relative to the centre of the tile `mt` describes
   auto commit = [&](const TileMeta& mt, const StageRegs<3>& sr, float4* img) {
     const float ox = __int_as_float(mt.centre[0]), oy = __int_as_float(mt.centre[1]), oz = __int_as_float(mt.centre[2]);
@@ -590,9 +618,9 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     });
   };
   // the sweep of one staged tile: table m, image A
-  auto sweep = [&](const TileMeta& m, const float4* __restrict__ A) {
+  auto sweep = [&](const TileMeta& m, const float4* __restrict__ A, bool force_global) {
     DSL_STAMP(d2);
-    const bool ovf = m.overflow != 0;
+    const bool ovf = m.overflow != 0 || force_global;
     const int ntarg = m.tprefix[kTB * kTB];
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
     // Targets are taken kTBlock at a time, one lane each.  A tile's LDS slot is held for as long as
@@ -626,10 +654,18 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
           const bool prefilter = __builtin_amdgcn_ballot_w64(far_lane) == 0ull;
           // SPHField.Density's loop body for one candidate record (sph_field.go:164-170): exactly the
           // operations of k_density<false>; a pad record or the particle itself adds +0
+          // (x^2 / h^2 by exact_div: the constant's reciprocal refinement is hoisted; bit for bit `/` on this tile)
+          const ExactDivisor Dhh = exact_divisor_uniform(c.hh);
           auto add = [&](const float4& cnd, bool counts) {
             const float dx = me.x - cnd.x, dy = me.y - cnd.y, dz = me.z - cnd.z;
             const float dist = dsl_sqrt<false>(dist2<false>(dx, dy, dz));
-            float w = kern_F<false>(c, dist);
+            float w = 0.0f;  // kern_F<false> (std_kernel.go:33-39)
+            if (!(dist >= c.h)) {
+              const float xx = dist * dist;
+              const float q = 1.0f - exact_div(xx, Dhh);
+              const float aq = c.A * q;
+              w = aq * q;
+            }
             w = counts ? w : 0.0f;
             const float mw = c.mass * w;
             density = density + mw;
@@ -848,7 +884,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
       }
       DSL_STAMP(d1b);
       DSL_STAMP_ADD(12, d1, d1b);  // next tile: load issue
-      sweep(metas[mc], Abuf[cur]);
+      sweep(metas[mc], Abuf[cur], false);
       DSL_STAMP(d4);
       if (stage_next) commit(metas[mn], sr, Abuf[cur ^ 1]);
       if (have_nn) tile_meta_store(metas[mnn], table_word);
@@ -868,14 +904,18 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
       have = feed.pop(di);
       int table_word = 0;
       if (have) table_word = tile_meta_request(desc, di);
+      bool unsafe = EXACT && !exact_div_ok(c.h);
       if (!m.overflow) {
         StageRegs<3> sr;
         stage_issue<3>(m, load4, sr);
         commit(m, sr, Abuf[0]);
+        if constexpr (EXACT) unsafe |= !stage_values_ok<3, 3>(m, sr);
       }
       if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
-      __syncthreads();
-      sweep(m, Abuf[0]);
+      bool force_global = false;
+      if constexpr (EXACT) force_global = __syncthreads_or(unsafe ? 1 : 0) != 0;
+      else __syncthreads();
+      sweep(m, Abuf[0], force_global);
     }
   }
 }
@@ -952,8 +992,11 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     }
     DSL_STAMP(t1b);
     DSL_STAMP_ADD(10, t1, t1b);  // first-pass mask word requests
+    // EXACT: the walk divides with exact_div (sph_device.hpp), which equals `/` bit for bit while every staged
+    // coordinate is 0 or between 2^-20 and 2^20 in magnitude; a tile with any other value takes the global sweep
+    bool unsafe = EXACT && !exact_div_ok(c.h);
     if (!nolds) {
-      stage_rows<8>(
+      const bool values_ok = stage_rows<8, EXACT>(
           m,
           [&](int g, float4* o) {
             o[0] = load4u(pin.x + g);
@@ -1005,10 +1048,13 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             A[slot] = a;
             if constexpr (WANT_V || WANT_XS) B[slot] = b;
           });
+      if constexpr (EXACT) unsafe |= !values_ok;
     }
     DSL_STAMP(t1c);
     if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
-    __syncthreads();
+    bool slow = nolds;  // this tile's targets take the global-memory sweep
+    if constexpr (EXACT) slow = (__syncthreads_or(unsafe ? 1 : 0) != 0) || nolds;
+    else __syncthreads();
     DSL_STAMP(t1d);
     DSL_STAMP_ADD(11, t1c, t1d);  // barrier behind the staging
     DSL_STAMP(t2);
@@ -1032,7 +1078,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
         // are unconditional and the rare unstaged tile overrides them, so that the compiler keeps
         // LDS and global loads apart instead of merging them into flat loads)
         {
-          const int own = nolds ? 0 : tt.own;
+          const int own = slow ? 0 : tt.own;
           const float4 a = A[own];
           px = a.x;
           py = a.y;
@@ -1046,12 +1092,12 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             vz = b.z;
           }
         }
-        if (nolds) {
+        if (slow) {
           px = pin.x[g];
           py = pin.y[g];
           pz = pin.z[g];
         }
-        if (nolds || !(WANT_V || WANT_XS)) {
+        if (slow || !(WANT_V || WANT_XS)) {
           vx = vin.x[g];
           vy = vin.y[g];
           vz = vin.z[g];
@@ -1078,7 +1124,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       if (owned) {
         float gx = 0.f, gy = 0.f, gz = 0.f, lx_ = 0.f, ly_ = 0.f, lz_ = 0.f;
         float cohx = 0.f, cohy = 0.f, cohz = 0.f;  // cohesion sum
-        if (!nolds) {
+        if (!slow) {
           if constexpr (WANT_G || WANT_V || WANT_XS) {
             const float pti = WANT_G ? pti_staged : 0.f;
             const float ninvh = -c.inv_h;
@@ -1105,13 +1151,24 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // EXACT: the loop bodies of SPHField.Gradient (sph_field.go:183-199), LaplacianForce (:259-266) and
             // the build-defined sums for one candidate, operation by operation as force_sweep<false> has them;
             // the particle itself, a pad record and a candidate at dist >= h add +0
+            // (divisions: exact_div -- the divisor's reciprocal refinement shared by the three quotients dx, dy, dz / dist,
+            // dist / h formed once for O1D and O2D, x^2 / h^2 with the constant's refinement hoisted; bit for bit `/` on
+            // a tile that passed exact_div_ok.  188 -> ~150 VALU instructions per pair.)
+            const ExactDivisor Dh = exact_divisor_uniform(c.h), Dhh = exact_divisor_uniform(c.hh);
             auto accum_exact = [&](const PairRec& rec) {
               const float4 a = rec.a, b = rec.b;
               const float dx = a.x - px, dy = a.y - py, dz = a.z - pz;  // dir = x_j - x_i (sph_field.go:189)
               const float dist = dsl_sqrt<false>(dist2<false>(dx, dy, dz));
               const bool in = rec.idx != own_rec && dist < c.h;
+              const float q1 = 1.0f - exact_div(dist, Dh);  // 1 - x/h of O1D and O2D (std_kernel.go:54-71)
               if constexpr (WANT_XS) {
-                const float fw = kern_F<false>(c, dist);
+                float fw = 0.0f;  // kern_F<false> (std_kernel.go:33-39)
+                if (!(dist >= c.h)) {
+                  const float xx = dist * dist;
+                  const float q = 1.0f - exact_div(xx, Dhh);
+                  const float aq = c.A * q;
+                  fw = aq * q;
+                }
                 const float ws = c.mass * fw;
                 const float tsx = dx * ws, tsy = dy * ws, tsz = dz * ws;
                 cohx = cohx + (in ? tsx : 0.0f);
@@ -1125,12 +1182,15 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               }
               if constexpr (WANT_G) {
                 float nx = 0.f, ny = 0.f, nz = 0.f;  // vector.go:322-331 Norm
+                const ExactDivisor Dd = exact_divisor(dist);
+                const float ex = exact_div(dx, Dd), ey = exact_div(dy, Dd), ez = exact_div(dz, Dd);
                 if (dist != 0.0f) {
-                  nx = dx / dist;
-                  ny = dy / dist;
-                  nz = dz / dist;
+                  nx = ex;
+                  ny = ey;
+                  nz = ez;
                 }
-                const float sgrad = -kern_O1D<false>(c, dist);  // std_kernel.go:74-76 Grad
+                const float bq = c.B * q1;  // kern_O1D<false>
+                const float sgrad = -((dist >= c.h) ? 0.0f : bq * q1);  // std_kernel.go:74-76 Grad
                 const float ggx = nx * sgrad, ggy = ny * sgrad, ggz = nz * sgrad;
                 const float F = pti_staged + a.w;
                 const float tx = ggx * F, ty = ggy * F, tz = ggz * F;
@@ -1141,7 +1201,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               if constexpr (WANT_V) {
                 const float inv = WANT_XS ? 1.0f / b.w : b.w;
                 const float ux = (b.x - vx) * inv, uy = (b.y - vy) * inv, uz = (b.z - vz) * inv;
-                const float o2 = kern_O2D<false>(c, dist);
+                const float o2 = (dist > c.h) ? 0.0f : c.C * q1;  // kern_O2D<false>
                 const float tx = ux * o2, ty = uy * o2, tz = uz * o2;
                 if (c.visc_running_mass) {  // sph_field.go:265: (force + t) * m
                   const float sx = lx_ + tx, sy = ly_ + ty, sz = lz_ + tz;
@@ -1319,7 +1379,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               // 0 .. kMaskAhead at once, then one per step): a word comes from HBM -- the masks of 16M particles are
               // 640 MB -- and a single run's walk is over long before that round trip is.
 #ifndef DSL_FORCE_PF
-#define DSL_FORCE_PF 1
+#define DSL_FORCE_PF 8
 #endif
               constexpr int kMaskAhead = DSL_FORCE_PF;
               unsigned int wq[9];
@@ -1335,6 +1395,21 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? *word_of(s, kMaskHigh) : 0u;
               };
               unsigned int ahead2 = second_of(0, rn, jn, jen);
+#ifdef DSL_DIAG_OLD_AHEAD  // (bisecting aid: the r02 form of this loop, one word ahead in a scalar)
+              unsigned int ahead = wq[0];
+#pragma unroll
+              for (int s = 0; s < 9; ++s) {
+                const unsigned int word = ahead, word2 = ahead2;
+                const int j = jn, je = jen, ri = rn;
+                if (s < 8) {
+                  rn = run_of(s + 1);
+                  if (runs_masked != 0u) ahead = *word_of(s + 1, 0);
+                  run_bounds_of_row(row_of(s + 1), jn, jen);
+                  ahead2 = second_of(s + 1, rn, jn, jen);
+                }
+                walk_run(ri, j, je, word, word2);
+              }
+#else
 #pragma unroll
               for (int s = 0; s < 9; ++s) {
                 const unsigned int word = wq[s], word2 = ahead2;
@@ -1348,6 +1423,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 }
                 walk_run(ri, j, je, word, word2);
               }
+#endif
             } else {
 #pragma unroll 1
               for (int ri = sub; ri < 9; ri += k) {

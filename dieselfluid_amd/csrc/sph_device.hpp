@@ -84,6 +84,7 @@ struct DevStats {
   int pci_done;
   int max_cell_count;
   int band_missed;  // split slab step: an interior particle moved further than the split margin
+  int scan_stuck;   // k_scan_onepass gave up waiting for a predecessor tile (never in a healthy run): the build is void
 };
 
 // ---------------------------------------------------------------------------------
@@ -98,6 +99,43 @@ template <bool FAST>
 __device__ __forceinline__ float dsl_div(float a, float b) {
   if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
   else return a / b;
+}
+
+// IEEE float32 division with the divisor's part of the work shared (DSL_MATH_EXACT walks: three quotients by the same
+// dist per pair, and quotients by the constants h and h^2).  `n / d` compiles to v_div_scale x2, v_rcp, two fma that
+// refine the reciprocal, q = n r, three fma that correct q, v_div_fmas, v_div_fixup (LLVM's AMDGPU lowering of a
+// correctly rounded fdiv).  exact_divisor() is that sequence's divisor half (rcp + its refinement), exact_div() its
+// numerator half with v_div_scale left out and v_div_fmas as the plain fma it is when nothing was scaled -- the SAME
+// operations on the same values, so the same bits, whenever v_div_scale would have returned its operands unchanged:
+// d normal, 1/d normal, n = 0 or |n| >= 2^-103, n/d normal and below 2^96.  exact_div_ok() is the condition the tiled
+// EXACT kernels check per staged tile (coordinates and h between 2^-20 and 2^20 in magnitude, or exactly 0: every
+// nonzero coordinate difference is then >= 2^-43, every distance <= 2^22); a tile that fails it takes the
+// global-memory sweep, which divides with `/`.
+struct ExactDivisor {
+  float d, r1;
+};
+__device__ __forceinline__ ExactDivisor exact_divisor(float d) {
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e0 = __builtin_fmaf(-d, r0, 1.0f);
+  return ExactDivisor{d, __builtin_fmaf(e0, r0, r0)};
+}
+// the same for a wave-uniform divisor (h, h^2): both halves live in scalar registers
+__device__ __forceinline__ ExactDivisor exact_divisor_uniform(float d) {
+  const ExactDivisor D = exact_divisor(d);
+  return ExactDivisor{__uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(D.d))),
+                      __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(D.r1)))};
+}
+__device__ __forceinline__ float exact_div(float n, const ExactDivisor& D) {
+  const float q0 = n * D.r1;
+  const float e1 = __builtin_fmaf(-D.d, q0, n);
+  const float q1 = __builtin_fmaf(e1, D.r1, q0);
+  const float e2 = __builtin_fmaf(-D.d, q1, n);
+  const float q2 = __builtin_fmaf(e2, D.r1, q1);
+  return __builtin_amdgcn_div_fixupf(q2, D.d, n);
+}
+__device__ __forceinline__ bool exact_div_ok(float v) {
+  const float a = fabsf(v);
+  return v == 0.0f || (a >= 0x1p-20f && a <= 0x1p20f);  // (false for NaN / Inf)
 }
 
 // kernel/std_kernel.go:33-39  F(x) = x>=h ? 0 : A*q*q, q = 1 - x*x/(h*h)
