@@ -84,6 +84,7 @@ struct dsl_handle {
   // their ids at the slots the atomic ranks name, one byte per particle that marks their particles
   unsigned int* unordered = nullptr;
   int *sort_keys = nullptr, *sort_work = nullptr;
+  int* cell_keys = nullptr;  // kCellKeys ids per grid cell: the one-pass in-cell ordering (kernels_grid.hpp); DSL_CELL_KEYS=0: off
   float* stage = nullptr;
   DevStats* dstats = nullptr;
   int cur_pv = 0, cur_ids = 0, cur_f = 0, cur_pci = 0;
@@ -94,8 +95,11 @@ struct dsl_handle {
   bool dens_held = false;
   // the histogram / "cells to order" bitmap were handed to a build that may not have cleaned them again
   bool sort_scratch_dirty = false;
-  // exclusive prefix of the cell counts in one launch (k_scan_onepass) instead of three; DSL_SCAN_ONEPASS=0 turns it off
-  bool scan_onepass = true;
+  // exclusive prefix of the cell counts in one launch (k_scan_onepass) instead of three: DSL_SCAN_ONEPASS=1.  OFF by
+  // default: measured on MI355X it is 6 x SLOWER at 16.4M cells (0.46 against 0.077 ms), 3 x at 4M, 1.3 x at 1M --
+  // all 4004 tiles are resident at once, so the look-back is one long chain of agent-scope round trips through
+  // the eight XCDs' separate L2s (profiles/README.md, r03)
+  bool scan_onepass = false;
   unsigned long long* scan_status = nullptr;  // one word per 4096-cell tile
   unsigned long long* scan_ticket = nullptr;  // the ever-growing ticket counter
   int64_t steps = 0;
@@ -354,7 +358,8 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                        ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
-                       onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr);
+                       onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
+                       ordered ? h->cell_keys : nullptr, h->dcounter + 3);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
@@ -396,12 +401,12 @@ int build_grid(dsl_handle* h, bool carry_derived) {
                        (carry_derived && !h->press_zero) ? h->press : nullptr};
   const bool want_dest = derived[0] || derived[1] || derived[2];
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work),
-                  want_dest ? h->rank : nullptr};
+                  want_dest ? h->rank : nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
     hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
-    if (ordered)
-      hipLaunchKernelGGL(k_scatter_ordered, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank,
-                         h->cell_start);
+    if (ordered)  // (with key rows: the flag-gated fallback for cells of more than kCellKeys particles, a small grid)
+      hipLaunchKernelGGL(k_scatter_ordered, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
+                         h->stream, c, a, so, p, h->rank, h->cell_start);
   });
   if (rc) return rc;
   if (carry_derived) {
@@ -424,7 +429,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     rc = timed(h, DSL_K_TILE_LIST, [&] {
       hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, h->c, h->tg,
                          h->cell_start, h->tiles, h->n_tiles, h->n_tiles + 5, h->c.n_ptr ? h->dn : nullptr, h->tile_desc_of,
-                         h->unordered, h->ncell_pad / 32);
+                         h->unordered, h->ncell_pad / 32, h->dcounter + 3);
       // the tables of the non-empty tiles, once per build for every kernel that sweeps tiles
       hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, h->c, h->tg,
                          h->cell_start, h->tiles, h->n_tiles, h->tile_desc);
@@ -719,6 +724,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->scratch1);
   (void)hipFree(h->rank);
   (void)hipFree(h->sort_keys);
+  (void)hipFree(h->cell_keys);
   (void)hipFree(h->sort_work);
   (void)hipFree(h->unordered);
   (void)hipFree(h->cell_count);
@@ -877,6 +883,11 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     return bail(DSL_ERR_DEVICE);
   }
   h->lsh = params->neigh_mode == DSL_NEIGH_LSH_REF;
+  {
+    bool want_rows = !h->lsh;
+    if (const char* e = std::getenv("DSL_CELL_KEYS")) want_rows = want_rows && std::atoi(e) != 0;
+    if (want_rows && (rc = dev_alloc(h, &h->cell_keys, (size_t)h->ncell_pad * kCellKeys))) return bail(rc);
+  }
   if (h->lsh) {
     const int B = params->lsh_buckets;
     h->lsh_cap = params->lsh_bucket_size > kLshSamples ? params->lsh_bucket_size : kLshSamples;
@@ -1682,16 +1693,16 @@ int slab_pack_on(dsl_handle* h, hipStream_t st, float width_full, float width, b
   }
   const float* pa = h->c.slab_axis == 0 ? p.x : (h->c.slab_axis == 1 ? p.y : p.z);
   const int nblk = (h->cap + kPackChunk - 1) / kPackChunk;
-  hipLaunchKernelGGL(k_slab_count, dim3(nblk), dim3(kBlock), 0, st, h->c, sb, old_axis, pa, dev_lo ? 1 : 0,
-                     dev_hi ? 1 : 0, h->pack_counts);
-  hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(kOffsBlock), 0, st, h->pack_counts, nblk, dev_lo, dev_hi, cap_full,
-                     cap_x, h->dn + 5);
   CSoa3 pcip{nullptr, nullptr, nullptr}, pciv{nullptr, nullptr, nullptr};
   if (h->pci_active) {  // migrants take their predictor state along
     Soa3 a = mpcip(h), b = mpciv(h);
     pcip = CSoa3{a.x, a.y, a.z};
     pciv = CSoa3{b.x, b.y, b.z};
   }
+  hipLaunchKernelGGL(k_slab_count, dim3(nblk), dim3(kBlock), 0, st, h->c, sb, old_axis, pa, dev_lo ? 1 : 0,
+                     dev_hi ? 1 : 0, h->pack_counts);
+  hipLaunchKernelGGL(k_slab_offsets, dim3(1), dim3(kOffsBlock), 0, st, h->pack_counts, nblk, dev_lo, dev_hi, cap_full,
+                     cap_x, h->dn + 5);
   hipLaunchKernelGGL(k_slab_write, dim3(nblk), dim3(kBlock), 0, st, h->c, sb, old_axis, pa, p.x, p.y, p.z, v.x, v.y, v.z,
                      h->ids[h->cur_ids], dev_lo, dev_hi, cap_full, cap_x, h->pack_counts, dsl_slab_record_floats(h), pcip,
                      pciv);

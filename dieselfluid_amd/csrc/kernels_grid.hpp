@@ -14,6 +14,13 @@
 namespace dsl {
 
 constexpr int kBlock = 256;
+// in-cell ordering in ONE scatter pass (r03): k_cell_rank drops every particle's id into slot `rank` of its cell's own
+// kCellKeys-entry key row (cell_keys[cell][rank]; ranks of a cell are 0 .. count-1, so the first `count` entries of a
+// row are exactly this build's members), and k_scatter, for a cell that needs ordering, reads the row and counts the
+// smaller ids.  The row array costs kCellKeys x 4 bytes per GRID CELL (2.1 GB for the 16M scene's 16.4M cells -- of
+// 288 GB), touched only where particles are.  A cell with more members than a row holds falls back to the two-pass
+// form (k_scatter_ordered), launched as a small flag-gated grid.
+constexpr int kCellKeys = 32;
 constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lanes x int4
 
 // ---------------------------------------------------------------------------------
@@ -41,7 +48,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
                                                       const float* __restrict__ pz, const int* __restrict__ ids,
                                                       int* __restrict__ rank, int* __restrict__ cell_count,
                                                       unsigned int* __restrict__ unordered, DevStats* stats,
-                                                      int* __restrict__ n_tiles) {
+                                                      int* __restrict__ n_tiles, int* __restrict__ cell_keys,
+                                                      int* __restrict__ overfull) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   // the small counters of the later kernels of this build (the fullest-cell statistic of the scan, the tile-list
   // lengths): cleared here, at the head of the build, when the one-launch scan is in use (stats != nullptr)
@@ -74,7 +82,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
     if (ids != nullptr && (base != 0 || (breaks & mine) != 0ull)) atomicOr(&unordered[cell >> 5], 1u << (cell & 31));
   }
   base = __shfl(base, head_lane, kWave);
-  if (i < n) rank[i] = base + (lane - head_lane);  // (the scatter recomputes the cell: cheaper than 8 B of traffic)
+  const int r = base + (lane - head_lane);
+  if (i < n) rank[i] = r;  // (the scatter recomputes the cell: cheaper than 8 B of traffic)
+  if (cell_keys != nullptr && i < n && cell >= 0 && cell != c.ncell) {
+    if (r < kCellKeys) cell_keys[(size_t)cell * kCellKeys + r] = id;
+    else *overfull = 1;  // (rare: benign race, every writer stores 1)
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -180,9 +193,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
 
 // The same exclusive prefix in ONE launch (decoupled look-back): every block takes a ticket, scans its 4096-cell tile,
 // publishes the tile's sum, then adds up the sums its predecessors have published until it meets one that already
-// knows its own prefix.  The counts are read once (the three-launch form reads them twice) and two launches go:
-// 0.07 -> 0.04 ms at 16.4M cells, and a third of the scan's time on a slab rank or the 1M scene, where launches
-// are what the scan costs.
+// knows its own prefix.  The counts are read once (the three-launch form reads them twice) and two launches go.
+// MEASURED AND NOT USED (DSL_SCAN_ONEPASS=1 selects it): 0.46 ms against 0.077 at 16.4M cells, 0.112 against 0.035 at
+// 4M, 0.024 against 0.018 at 1M.  Every tile of the grid is resident at once here, so the prefixes travel down one chain
+// of ~60 look-back windows, each an agent-scope round trip (the XCDs' L2s are not coherent with each other).
 //   status[tile] = value | (generation * 4 + flag) << 32, flag 1 = the tile's own sum, 2 = its inclusive prefix;
 //   the generation is ticket / nb of an ever-growing 64-bit ticket counter, so nothing is ever cleared and a
 //   replayed hipGraph needs no new arguments.
@@ -316,6 +330,8 @@ struct ScatterOrder {
   int* keys;                      // ids at the atomic slots (marked cells only)
   unsigned char* later;           // per particle: 1 = belongs to a marked cell, k_scatter_ordered places it
   int* dest;                      // optional: final slot of every particle (to permute derived arrays)
+  const int* cell_keys;           // the cells' key rows written by k_cell_rank (nullptr: two-pass ordering only)
+  const int* overfull;            // set by k_cell_rank when some cell holds more than kCellKeys particles
 };
 // (No compacted work list: appending to one costs an atomic per wave on a single counter -- 250k
 // same-address atomics per 16M-particle build serialise in L2 and took 2.8 ms once the flow had
@@ -337,17 +353,54 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
   const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
   if (cell != c.ncell) {  // (a stale ghost is dropped)
     const int id = a.ids_src[i];
-    const int d = cell_start[cell] + rank[i];
+    const int s = cell_start[cell], r = rank[i];
+    int d = s + r;
     later = o.unordered != nullptr && ((o.unordered[cell >> 5] >> (cell & 31)) & 1u);
+    if (later && o.cell_keys != nullptr) {
+      const int cnt = cell_start[cell + 1] - s;
+      if (cnt <= kCellKeys) {  // the common case: the cell's ids are in its key row, count the smaller ones
+        const int4* row = reinterpret_cast<const int4*>(o.cell_keys + (size_t)cell * kCellKeys);
+        int below = 0;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {  // eight ids per trip (a cell holds ~8)
+          const int4 u = row[k0 / 4], w = row[k0 / 4 + 1];
+          const int key[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            below += (k0 + q < cnt && (key[q] < id || (key[q] == id && k0 + q < r))) ? 1 : 0;
+        }
+        d = s + below;
+        later = false;
+      }
+    }
     if (later) o.keys[d] = id;
     else scatter_move(a, o, i, d, id);
   }
-  if (o.unordered != nullptr) o.later[i] = later ? 1 : 0;
+  if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later ? 1 : 0;
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                             const int* __restrict__ rank,
                                                             const int* __restrict__ cell_start) {
+  if (o.cell_keys != nullptr) {
+    // fallback of the one-pass ordering: only the marked cells with more than kCellKeys members are left, and only
+    // if k_cell_rank has seen such a cell at all.  A small grid strides over the particles.
+    if (*o.overfull == 0) return;
+    const int n = live_n(c);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+      const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+      if (cell == c.ncell) continue;
+      const int s = cell_start[cell], e = cell_start[cell + 1];
+      if (e - s <= kCellKeys || !((o.unordered[cell >> 5] >> (cell & 31)) & 1u)) continue;
+      const int id = a.ids_src[i], mine = s + rank[i];
+      int below = 0;
+      for (int k = s; k < e; ++k) {
+        const int key = o.keys[k];
+        below += (key < id || (key == id && k < mine)) ? 1 : 0;
+      }
+      scatter_move(a, o, i, s + below, id);
+    }
+    return;
+  }
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c) || !o.later[i]) return;
   const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
@@ -669,6 +722,10 @@ __global__ __launch_bounds__(kBlock) void k_slab_write(DevConsts c, SlabBands sb
   }
 }
 
+// (r03, measured and removed: the same pack as ONE launch -- a block takes its place in the message with one atomic per
+// category, the last block out, found by a done-counter, writes the headers -- took 204 us instead of the 30 us of
+// count / offsets / write on a rank of 3M slots: ~1500 blocks' atomics on ONE done-counter serialise at ~130 ns
+// each.  The same lesson as the band counters of round 1; profiles/README.md.)
 __device__ __forceinline__ void slab_counts(const float* msg, int cap_full, int cap_x, int& nf, int& nx) {
   nf = __float_as_int(msg[0]);
   nx = __float_as_int(msg[1]);

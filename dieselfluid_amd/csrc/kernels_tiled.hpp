@@ -110,8 +110,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
                                                       int* __restrict__ tiles, int* __restrict__ n_tiles,
                                                       int* __restrict__ short_pass_tiles, int* __restrict__ n_live,
                                                       int* __restrict__ desc_of, unsigned int* __restrict__ unordered,
-                                                      int unordered_words) {
+                                                      int unordered_words, int* __restrict__ overfull) {
   const int lt = blockIdx.x * kBlock + threadIdx.x;  // list thread: tiles are enumerated box by box (TileGrid)
+  if (lt == 0) *overfull = 0;  // k_cell_rank's "a cell outgrew its key row" flag has been consumed by the scatter
   // the sort's "cells to order" bitmap (kernels_grid.hpp) has been consumed: clean for the next build
   // (64 cells per tile = two words per tile thread; saves the build a memset launch)
   if (unordered != nullptr) {
@@ -1279,6 +1280,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // of a wave SOME lane needs its second word: fetched here, inside the walk, that was one exposed
             // HBM latency per run and wave.)
             // the in-range bits of one mask word (or of a chunk of up to 32 unmasked candidates): bit b <-> record top - b
+            // the in-range bits of one mask word (or of a chunk of up to 32 unmasked candidates): bit b <-> record top - b
             auto walk_bits = [&](unsigned int mm, const int top) {
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: measures the per-tile fixed cost (set-up + staging + epilogue)
               mm = 0u;
@@ -1320,6 +1322,34 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 } while (more);
               }
             };
+            // The same with a second word (candidates 32-63 of a run that long, records top2 - b) in the SAME loop, a
+            // lane moving on to it when its first word is used up.  (The second words used to get a loop of their own
+            // behind the first: once the lattice has melted ~8 % of the runs are that long, so nearly every wave
+            // entered that second loop on nearly every run for the sake of one or two lanes -- set-up, one padded trip
+            // and all: most of the developed flow's +54 % in this kernel.)  FAST only: the sums are order-independent
+            // up to rounding.
+            auto walk_bits2 = [&](unsigned int mm, int top, unsigned int mm2, const int top2) {
+              auto take = [&]() {
+                const bool next_word = mm == 0u;
+                mm = next_word ? mm2 : mm;
+                top = next_word ? top2 : top;
+                mm2 = next_word ? 0u : mm2;
+                const int idx = mm != 0u ? top - __builtin_ctz(mm) : pad_rec;
+                mm &= mm - 1u;
+                return idx;
+              };
+              if (__builtin_amdgcn_ballot_w64((mm | mm2) != 0u) != 0ull) {
+                PairRec p = fetch(take());
+                bool more;
+                do {
+                  const PairRec q = fetch(take());
+                  accum(p);
+                  more = __builtin_amdgcn_ballot_w64((mm | mm2) != 0u) != 0ull;
+                  p = fetch(take());
+                  accum(q);
+                } while (more);
+              }
+            };
             // A run: its first 32 candidates in straight-line code -- on a lattice, and wherever no lane of the
             // wave has a run longer than that, this is all there is -- then, lane by lane, the chunks behind them
             // (the second mask word, or chunks of 32 with every bit set for a run without a mask).
@@ -1339,9 +1369,22 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                   walk_bits(has_mask ? word : all, from + (has_mask ? ((clen + 3) & ~3) : clen) - 1);
                 }
               };
-              chunk(j, first_word);
-              if (__builtin_amdgcn_ballot_w64(je - j > 32) != 0ull)
-                for (int from = j + 32; from < je; from += 32) chunk(from, second_word);
+              const bool any_long = __builtin_amdgcn_ballot_w64(je - j > 32) != 0ull;
+              bool both_words = false;  // some lane's run has a second word and every lane's masks cover its run
+              // (only in the pass-sharing instantiations -- the ones a melted lattice runs; the plain instantiation (a
+              // lattice at rest: no run is that long) would pay for the second copy of the walk in registers, i.e. occupancy)
+              if constexpr (!EXACT && SHARE && !SLAB) both_words = any_long && all_masked && __builtin_amdgcn_ballot_w64(je - j > 64) == 0ull;
+              if (both_words) {
+                if constexpr (!EXACT && SHARE && !SLAB) {  // (the slab instantiation is at its register limit: 20 bytes of scratch with it)
+                  const int clen1 = min(je - j, 32), rest = je - j - 32;
+                  const int clen2 = rest > 0 ? rest : 0;
+                  walk_bits2(first_word, j + ((clen1 + 3) & ~3) - 1, rest > 0 ? second_word : 0u, j + 32 + ((clen2 + 3) & ~3) - 1);
+                }
+              } else {
+                chunk(j, first_word);
+                if (any_long)
+                  for (int from = j + 32; from < je; from += 32) chunk(from, second_word);
+              }
             };
             if constexpr (!SHARED) {
               // The wave spends, on every run, as many iterations as its busiest lane has neighbours

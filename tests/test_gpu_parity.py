@@ -52,10 +52,15 @@ def test_density_pass(math_mode, tol):
     assert _agree(rho, ora.densities(), tol)
 
 
-def test_cells_are_ordered_by_particle_id():
-    """The counting sort leaves every cell ascending in particle id (dsl_params.sort_unordered = 0)."""
+@pytest.mark.parametrize("h_over_dx", [2.0, 5.0])
+def test_cells_are_ordered_by_particle_id(h_over_dx):
+    """The counting sort leaves every cell ascending in particle id (dsl_params.sort_unordered = 0).  h = 2 dx: ~8
+    particles per cell, ordered in the scatter pass itself from the cells' key rows; h = 5 dx: ~125 per cell, more
+    than a key row holds (kCellKeys = 32): the flag-gated two-pass fallback."""
     from dieselfluid_amd import scenes
-    p, pos = scenes.dambreak_scene(16, math_mode=FAST)
+    p, pos = scenes.dambreak_scene(16, math_mode=FAST, h_over_dx=h_over_dx)
+    if h_over_dx > 2.0:
+        p.dt = p.dt * 0.2
     rng = np.random.default_rng(5)
     perm = rng.permutation(pos.shape[0])  # ids unrelated to the position in the lattice
     eng = _engine(p)
@@ -64,9 +69,12 @@ def test_cells_are_ordered_by_particle_id():
     eng.wcsph_step(3)
     eng.nn()
     ids, cs = eng.download_ids(), eng.download_cell_start()
+    assert np.array_equal(np.sort(ids), np.arange(pos.shape[0]))  # a permutation: nobody lost, nobody twice
+    assert (np.diff(cs).max() > 32) == (h_over_dx > 2.0)
     cell_of_slot = np.repeat(np.arange(cs.size - 1), np.diff(cs))
     same_cell = cell_of_slot[1:] == cell_of_slot[:-1]
     assert np.all(np.diff(ids)[same_cell] > 0)
+    eng.close()
 
 
 @pytest.mark.parametrize("math_mode", [EXACT, FAST])
