@@ -67,6 +67,17 @@ struct TileMeta {
 constexpr int kMetaInts = 340;
 static_assert(sizeof(TileMeta) == kMetaInts * sizeof(int), "TileMeta is copied as kMetaInts dwords");
 
+// __syncthreads() with the wave's own LDS traffic drained first, stated explicitly.  hipcc leaves the
+// `s_waitcnt lgkmcnt(0)` in front of an s_barrier to its waitcnt pass, and at the head of the double-buffered loops
+// below (LDS writes at the END of the loop body, the barrier at its HEAD, reached over the back edge) that pass
+// emitted none: the ISA had `ds_write_b128 ... s_branch ... s_barrier`.  A wave could then pass the barrier while a
+// sibling's last records or table words were still on their way, and one 16M run in three met a stale record
+// within a few thousand steps (densities off, then a blow-up): profiles/README.md, r03.
+__device__ __forceinline__ void sync_lds() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 struct TileGrid {
   int tnx, tny, tnz, ntiles;
   // Enumeration order of the tile list (k_tile_list): boxes of bx x by x bz tiles, the boxes x-fastest and the
@@ -169,14 +180,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
     mask_of[l] = __ballot(member(l));
     if (lane == 0) wave_count[wid][l] = __builtin_popcountll(mask_of[l]);
   }
-  __syncthreads();
+  sync_lds();
   if (threadIdx.x <= kTileLists) {
     int total = 0;
     for (int w = 0; w < kBlock / kWave; ++w) total += wave_count[w][threadIdx.x];
     int* counter = threadIdx.x == kTileLists ? short_pass_tiles : n_tiles + threadIdx.x;
     block_base[threadIdx.x] = total > 0 ? atomicAdd(counter, total) : 0;
   }
-  __syncthreads();
+  sync_lds();
   int pos0 = 0;
 #pragma unroll
   for (int l = 0; l < kTileLists; ++l) {
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   if constexpr (DB) {
     bool have_next = feed.pop(di);
     int table_word = have_next ? tile_meta_request(desc, di) : 0;
-    __syncthreads();  // the first tile's table is visible
+    sync_lds();  // the first tile's table is visible
     {                 // the first tile is staged in the open: nothing to hide it under yet
       StageRegs<3> sr;
       if (!metas[0].overflow) {
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
     int mc = 0, mn = 1, mnn = 2;  // tables of this tile, the next one, the one after
     for (int cur = 0; have; cur ^= 1) {
       DSL_STAMP(d0);
-      __syncthreads();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
+      sync_lds();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
       DSL_STAMP(d1);
       DSL_STAMP_ADD(4, d0, d1);
       StageRegs<3> sr;
@@ -901,7 +912,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
   } else {
     for (int cur = 0; have; cur ^= 1) {
       TileMeta& m = metas[cur];
-      __syncthreads();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
+      sync_lds();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
       have = feed.pop(di);
       int table_word = 0;
       if (have) table_word = tile_meta_request(desc, di);
@@ -914,8 +925,11 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
       }
       if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
       bool force_global = false;
-      if constexpr (EXACT) force_global = __syncthreads_or(unsafe ? 1 : 0) != 0;
-      else __syncthreads();
+      if constexpr (EXACT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (see sync_lds)
+        force_global = __syncthreads_or(unsafe ? 1 : 0) != 0;
+      }
+      else sync_lds();
       sweep(m, Abuf[0], force_global);
     }
   }
@@ -969,12 +983,12 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
   // is put into the other LDS copy behind it: a tile starts with ONE barrier and its table in place.
   int di = 0;
   bool have = feed.pop(di);
-  if (phase == 1) __syncthreads();  // (the first phase's last sweep may still be reading its table)
+  if (phase == 1) sync_lds();  // (the first phase's last sweep may still be reading its table)
   if (have) tile_meta_store(metas[0], tile_meta_request(desc, di));
   for (int cur = 0; have; cur ^= 1) {
     TileMeta& m = metas[cur];
     DSL_STAMP(t0);
-    __syncthreads();  // the previous tile's sweep is over, this tile's table is visible
+    sync_lds();  // the previous tile's sweep is over, this tile's table is visible
     have = feed.pop(di);
     int table_word = 0;
     if (have) table_word = tile_meta_request(desc, di);
@@ -1054,8 +1068,11 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     DSL_STAMP(t1c);
     if (have) tile_meta_store(metas[cur ^ 1], table_word);  // (requested before the staging loads: it has landed with them)
     bool slow = nolds;  // this tile's targets take the global-memory sweep
-    if constexpr (EXACT) slow = (__syncthreads_or(unsafe ? 1 : 0) != 0) || nolds;
-    else __syncthreads();
+    if constexpr (EXACT) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (see sync_lds)
+      slow = (__syncthreads_or(unsafe ? 1 : 0) != 0) || nolds;
+    }
+    else sync_lds();
     DSL_STAMP(t1d);
     DSL_STAMP_ADD(11, t1c, t1d);  // barrier behind the staging
     DSL_STAMP(t2);
@@ -1373,7 +1390,9 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               bool both_words = false;  // some lane's run has a second word and every lane's masks cover its run
               // (only in the pass-sharing instantiations -- the ones a melted lattice runs; the plain instantiation (a
               // lattice at rest: no run is that long) would pay for the second copy of the walk in registers, i.e. occupancy)
+#ifndef DSL_NO_TWO_WORD
               if constexpr (!EXACT && SHARE && !SLAB) both_words = any_long && all_masked && __builtin_amdgcn_ballot_w64(je - j > 64) == 0ull;
+#endif
               if (both_words) {
                 if constexpr (!EXACT && SHARE && !SLAB) {  // (the slab instantiation is at its register limit: 20 bytes of scratch with it)
                   const int clen1 = min(je - j, 32), rest = je - j - 32;
@@ -1816,7 +1835,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
     tile_meta_store(metas[0], tile_meta_request(desc, di));
     bool have_next = feed.pop(di);
     int table_word = have_next ? tile_meta_request(desc, di) : 0;
-    __syncthreads();  // the first tile's table is visible
+    sync_lds();  // the first tile's table is visible
     {
       StageRegs<3> sr;
       if (!metas[0].overflow) {
@@ -1827,7 +1846,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
     if (have_next) tile_meta_store(metas[1], table_word);
     int mc = 0, mn = 1, mnn = 2;  // tables of this tile, the next one, the one after
     for (int cur = 0; have; cur ^= 1) {
-      __syncthreads();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
+      sync_lds();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
       StageRegs<3> sr;
       bool have_nn = false, stage_next = false;
       table_word = 0;
