@@ -100,6 +100,7 @@ struct dsl_handle {
   // all 4004 tiles are resident at once, so the look-back is one long chain of agent-scope round trips through
   // the eight XCDs' separate L2s (profiles/README.md, r03)
   bool scan_onepass = false;
+  int max_persistent_blocks = 0;  // DSL_PERSISTENT_BLOCKS (tests)
   unsigned long long* scan_status = nullptr;  // one word per 4096-cell tile
   unsigned long long* scan_ticket = nullptr;  // the ever-growing ticket counter
   int64_t steps = 0;
@@ -469,6 +470,10 @@ bool use_tiled(const dsl_handle* h) {
 }
 int persistent_grid(const dsl_handle* h, int blocks_per_cu) {
   int g = 256 * blocks_per_cu;
+  // (tests: DSL_PERSISTENT_BLOCKS caps the grid, so that a small scene makes every workgroup walk MANY tiles -- the
+  // tile-to-tile hand-over inside a workgroup is where the double-buffered loops can go wrong, and a test scene of a
+  // few hundred tiles otherwise gives each workgroup one)
+  if (h->max_persistent_blocks > 0 && g > h->max_persistent_blocks) g = h->max_persistent_blocks;
   if (g > h->tg.ntiles) g = h->tg.ntiles;
   g = (g + 7) & ~7;  // the XCD walk deals tiles in eighths
   return g < 8 ? 8 : g;
@@ -907,6 +912,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if (const char* e = std::getenv("DSL_SCAN_ONEPASS")) h->scan_onepass = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DSL_PERSISTENT_BLOCKS")) h->max_persistent_blocks = std::atoi(e);
   {  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
     int bx = 8, by = 4, bz = 4;
     if (const char* e = std::getenv("DSL_TILE_BOX")) {  // "bx,by,bz" (A/B runs); "0" = the tile grid's linear order

@@ -1339,34 +1339,6 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 } while (more);
               }
             };
-            // The same with a second word (candidates 32-63 of a run that long, records top2 - b) in the SAME loop, a
-            // lane moving on to it when its first word is used up.  (The second words used to get a loop of their own
-            // behind the first: once the lattice has melted ~8 % of the runs are that long, so nearly every wave
-            // entered that second loop on nearly every run for the sake of one or two lanes -- set-up, one padded trip
-            // and all: most of the developed flow's +54 % in this kernel.)  FAST only: the sums are order-independent
-            // up to rounding.
-            auto walk_bits2 = [&](unsigned int mm, int top, unsigned int mm2, const int top2) {
-              auto take = [&]() {
-                const bool next_word = mm == 0u;
-                mm = next_word ? mm2 : mm;
-                top = next_word ? top2 : top;
-                mm2 = next_word ? 0u : mm2;
-                const int idx = mm != 0u ? top - __builtin_ctz(mm) : pad_rec;
-                mm &= mm - 1u;
-                return idx;
-              };
-              if (__builtin_amdgcn_ballot_w64((mm | mm2) != 0u) != 0ull) {
-                PairRec p = fetch(take());
-                bool more;
-                do {
-                  const PairRec q = fetch(take());
-                  accum(p);
-                  more = __builtin_amdgcn_ballot_w64((mm | mm2) != 0u) != 0ull;
-                  p = fetch(take());
-                  accum(q);
-                } while (more);
-              }
-            };
             // A run: its first 32 candidates in straight-line code -- on a lattice, and wherever no lane of the
             // wave has a run longer than that, this is all there is -- then, lane by lane, the chunks behind them
             // (the second mask word, or chunks of 32 with every bit set for a run without a mask).
@@ -1386,24 +1358,12 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                   walk_bits(has_mask ? word : all, from + (has_mask ? ((clen + 3) & ~3) : clen) - 1);
                 }
               };
-              const bool any_long = __builtin_amdgcn_ballot_w64(je - j > 32) != 0ull;
-              bool both_words = false;  // some lane's run has a second word and every lane's masks cover its run
-              // (only in the pass-sharing instantiations -- the ones a melted lattice runs; the plain instantiation (a
-              // lattice at rest: no run is that long) would pay for the second copy of the walk in registers, i.e. occupancy)
-#ifndef DSL_NO_TWO_WORD
-              if constexpr (!EXACT && SHARE && !SLAB) both_words = any_long && all_masked && __builtin_amdgcn_ballot_w64(je - j > 64) == 0ull;
-#endif
-              if (both_words) {
-                if constexpr (!EXACT && SHARE && !SLAB) {  // (the slab instantiation is at its register limit: 20 bytes of scratch with it)
-                  const int clen1 = min(je - j, 32), rest = je - j - 32;
-                  const int clen2 = rest > 0 ? rest : 0;
-                  walk_bits2(first_word, j + ((clen1 + 3) & ~3) - 1, rest > 0 ? second_word : 0u, j + 32 + ((clen2 + 3) & ~3) - 1);
-                }
-              } else {
-                chunk(j, first_word);
-                if (any_long)
-                  for (int from = j + 32; from < je; from += 32) chunk(from, second_word);
-              }
+              // (r03, measured and removed: walking a long run's second word in the SAME loop as the first -- a lane moving
+              // on to it when its first word is used up -- instead of in a loop of its own behind it: developed-flow force
+              // 1.42 ms with, 1.40 without.  The second loops are not where the developed flow's +54 % comes from.)
+              chunk(j, first_word);
+              if (__builtin_amdgcn_ballot_w64(je - j > 32) != 0ull)
+                for (int from = j + 32; from < je; from += 32) chunk(from, second_word);
             };
             if constexpr (!SHARED) {
               // The wave spends, on every run, as many iterations as its busiest lane has neighbours

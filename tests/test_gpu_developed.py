@@ -155,3 +155,40 @@ def test_full_size_pcisph_properties(n3, extra, steps):
     assert st.max_vel >= vmax * (1 - 1e-6)  # maxVel is a running maximum (fluid.go:186-191)
     assert np.array_equal(eng.download("pressures"), np.zeros(n, dtype=np.float32))  # Update: Press = 0 (fluid.go:192)
     eng.close()
+
+
+@pytest.mark.parametrize("method", ["wcsph", "pcisph"])
+def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method, monkeypatch):
+    """The persistent tile kernels hand a workgroup one tile after another (double-buffered LDS image, rotating tile
+    tables: kernels_tiled.hpp).  A scene of a few hundred tiles gives every workgroup ONE tile, so that hand-over is
+    never exercised by the other tests -- round 3 shipped a barrier without its LDS drain there and only a 10000-step
+    16M soak noticed.  Here the grid is capped at 8 workgroups (DSL_PERSISTENT_BLOCKS), 60+ tiles each, and the run
+    must give the same BITS as the uncapped engine: FAST arithmetic does not depend on which workgroup sweeps a tile."""
+    from dieselfluid_amd import SPHEngine, scenes
+    n3 = 64
+    p, pos = scenes.dambreak_scene(n3, math_mode=1)
+    if method == "pcisph":
+        p.pci_max_iters = 4
+        p.eos_w = p.eos_w / 4
+        p.delta = 1.0e-7
+    res = []
+    for cap in (0, 8):
+        if cap:
+            monkeypatch.setenv("DSL_PERSISTENT_BLOCKS", str(cap))
+        else:
+            monkeypatch.delenv("DSL_PERSISTENT_BLOCKS", raising=False)
+        eng = SPHEngine(p, device=0)
+        eng.upload("positions", pos)
+        eng.reset_forces()
+        if method == "pcisph":
+            eng.pcisph_begin()
+            for _ in range(6):
+                eng.pcisph_step(10)
+        else:
+            for _ in range(10):
+                eng.wcsph_step(60)
+        res.append((eng.download("positions"), eng.download("velocities"), eng.download("densities")))
+        assert np.isfinite(res[-1][0]).all()
+        eng.close()
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
