@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               for (int s = 0; s < 9; ++s) wq[s] = 0u;
               wq[0] = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);  // (not behind runs_masked)
 #pragma unroll
-              for (int s = 1; s < kMaskAhead && s < 9; ++s)
+              for (int s = 1; s <= kMaskAhead && s < 9; ++s)
                 if (runs_masked != 0u) wq[s] = *word_of(s, 0);
               int jn, jen;
               run_bounds_of_row(row_of(0), jn, jen);
@@ -1432,12 +1432,18 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 walk_run(ri, j, je, word, word2);
               }
 #else
+              // (r03, measured and removed: a two-run WINDOW for the developed flow -- the wave walks run s until every lane
+              // is through with it, but a lane without bits left in run s takes bits of its run s+1 meanwhile, second words
+              // as steps 9..17 of the same window -- because there the busiest lane of EACH run sets the pace: 7.7e8 VALU
+              // instructions per launch against 4.4e8 on the lattice, ~80 pair iterations per target for ~36 neighbours
+              // (profiles/r03_developed_pmc.txt).  Two cursors cost five more VALU per pair and the window moves through
+              // 18 steps: force 1.56 ms with it, 1.40 without.)
 #pragma unroll
               for (int s = 0; s < 9; ++s) {
                 const unsigned int word = wq[s], word2 = ahead2;
                 const int j = jn, je = jen, ri = rn;
-                if (s + kMaskAhead < 9)
-                  if (runs_masked != 0u) wq[s + kMaskAhead] = *word_of(s + kMaskAhead, 0);
+                if (s + kMaskAhead + 1 < 9)
+                  if (runs_masked != 0u) wq[s + kMaskAhead + 1] = *word_of(s + kMaskAhead + 1, 0);
                 if (s < 8) {
                   rn = run_of(s + 1);
                   run_bounds_of_row(row_of(s + 1), jn, jen);
