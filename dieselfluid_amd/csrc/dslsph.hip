@@ -100,6 +100,7 @@ struct dsl_handle {
   // all 4004 tiles are resident at once, so the look-back is one long chain of agent-scope round trips through
   // the eight XCDs' separate L2s (profiles/README.md, r03)
   bool scan_onepass = false;
+  bool density_pair = true;  // FAST density with two targets per lane (DSL_DENSITY_PAIR=0: the lane-per-target kernel)
   int max_persistent_blocks = 0;  // DSL_PERSISTENT_BLOCKS (tests)
   unsigned long long* scan_status = nullptr;  // one word per 4096-cell tile
   unsigned long long* scan_ticket = nullptr;  // the ever-growing ticket counter
@@ -489,6 +490,15 @@ int density_pass(dsl_handle* h) {
 #define DSL_LAUNCH_DENSITY(KERNEL)                                                                                   \
   hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, \
                      h->tile_desc, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap)
+      if (h->density_pair) {  // two targets per lane (kernels_tiled.hpp: k_density_pair), 256-thread workgroups, four per CU
+#define DSL_LAUNCH_PAIR(KERNEL)                                                                                      \
+  hipLaunchKernelGGL(KERNEL, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, \
+                     h->tile_desc, h->cell_start, bnd_of(h), p, h->rho, h->pterm, h->nmask, h->cap)
+        if (c.slab_axis < 0) DSL_LAUNCH_PAIR(k_density_pair<false>);
+        DSL_LAUNCH_PAIR(k_density_pair<true>);
+#undef DSL_LAUNCH_PAIR
+        return;
+      }
       if (c.slab_axis < 0) DSL_LAUNCH_DENSITY(k_density_tiled<false>);
       DSL_LAUNCH_DENSITY(k_density_tiled<true>);
 #undef DSL_LAUNCH_DENSITY
@@ -912,6 +922,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if (const char* e = std::getenv("DSL_SCAN_ONEPASS")) h->scan_onepass = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DSL_DENSITY_PAIR")) h->density_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PERSISTENT_BLOCKS")) h->max_persistent_blocks = std::atoi(e);
   {  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
     int bx = 8, by = 4, bz = 4;

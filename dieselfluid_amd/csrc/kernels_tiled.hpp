@@ -58,13 +58,17 @@ struct TileMeta {
   int overflow;
   int tile;                       // the tile's id in the tile grid
   int centre[3];                  // float bits: the tile centre in world coordinates (origin of the tile-relative records)
-  int pad_;                       // 340 ints: a whole number of 16-byte pieces
+  int pad_;
+  // k_density_pair: prefix, over the 16 interior rows, of the rows' PAIR SLOTS (a slot = two targets of one cell, or a
+  // cell's odd one out: sum over the row's four cells of (count + 1) / 2)
+  int pprefix[kTB * kTB + 1];
+  int pad2_[3];                   // 360 ints: a whole number of 16-byte pieces
 };
 // A tile's table is built ONCE per neighbour build, by k_tile_desc, into a global array of these
 // (one per non-empty tile, in the order of tile list 0); the sweeping kernels copy it into LDS, one
 // dword per lane, one tile ahead of its use.  (Each kernel used to derive it again for every tile it
 // visited -- seven dependent loads per row, a scan and two more barriers in front of every staging.)
-constexpr int kMetaInts = 340;
+constexpr int kMetaInts = 360;
 static_assert(sizeof(TileMeta) == kMetaInts * sizeof(int), "TileMeta is copied as kMetaInts dwords");
 
 // __syncthreads() with the wave's own LDS traffic drained first, stated explicitly.  hipcc leaves the
@@ -248,6 +252,12 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
     const int inc = wave_inclusive_scan(v);  // LDS offsets: rows are kTPad apart
     const int tv = interior ? r.s[kTB + 1] - r.s[1] : 0;
     const int tinc = wave_inclusive_scan(tv);  // targets: interior rows, interior cells
+    int pv = 0;  // pair slots of the row's four interior cells
+    if (interior) {
+#pragma unroll
+      for (int k = 1; k <= kTB; ++k) pv += (r.s[k + 1] - r.s[k] + 1) >> 1;
+    }
+    const int pinc = wave_inclusive_scan(pv);
     if (row) {
       out->row_gs[lane] = r.s[0];
       out->row_len[lane] = len;
@@ -259,6 +269,7 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
       if (interior) {
         const int ir = (rz - 1) * kTB + (ry - 1), t0 = tinc - tv;  // the row's first target
         out->tprefix[ir] = t0;
+        out->pprefix[ir] = pinc - pv;
         out->trow[ir] = make_int4(r.s[1] - t0, lds0 + (r.s[1] - r.s[0]) - t0,
                                   (t0 + (r.s[2] - r.s[1])) | ((t0 + (r.s[3] - r.s[1])) << 16), t0 + (r.s[4] - r.s[1]));
       }
@@ -268,6 +279,7 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
         // indices fit 16 bits as long as the staged records do -- the targets are among them)
         out->overflow = inc > kTCap ? 1 : 0;
         out->tprefix[kTB * kTB] = tinc;
+        out->pprefix[kTB * kTB] = pinc;
         out->tile = tile;
         out->centre[0] = __float_as_int(c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h);
         out->centre[1] = __float_as_int(c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h);
@@ -444,16 +456,17 @@ struct StageRegs {
   float4 v[NF];  // v[a] = elements g .. g+3 of source array a
 };
 // issue: nothing waits here.  Needs row_gs / row_len only.  load4(g, out[NF]): the quad loads at slot g.
+// (vt: the quad slot this lane stages, threadIdx.x in the 512-thread kernels; the 256-thread pair kernel calls twice)
 template <int NF, class Load4>
-__device__ __forceinline__ void stage_issue(const TileMeta& m, Load4&& load4, StageRegs<NF>& sr) {
-  const int t = threadIdx.x, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
+__device__ __forceinline__ void stage_issue(const TileMeta& m, Load4&& load4, StageRegs<NF>& sr, int vt = -1) {
+  const int t = vt < 0 ? (int)threadIdx.x : vt, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
   if (r < kTRows && 4 * k < m.row_len[r]) load4(m.row_gs[r] + 4 * k, sr.v);
 }
 // commit: registers -> LDS records, the rest of rows longer than 56, the pad records.
 // load1(g, out[NF]): one record; store(slot, rec[NF], real)
 template <int NF, class Load1, class Store>
-__device__ __forceinline__ void stage_commit(const TileMeta& m, const StageRegs<NF>& sr, Load1&& load1, Store&& store) {
-  const int t = threadIdx.x, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
+__device__ __forceinline__ void stage_commit(const TileMeta& m, const StageRegs<NF>& sr, Load1&& load1, Store&& store, int vt = -1) {
+  const int t = vt < 0 ? (int)threadIdx.x : vt, r = t / kQuadsPerRow, k = t - r * kQuadsPerRow;
   if (r >= kTRows) return;
   const int len = m.row_len[r], ls = m.row_lds[r];
 #pragma unroll
@@ -529,20 +542,20 @@ __device__ __forceinline__ bool share_wanted(const int* __restrict__ stats) {
 // SHARE = false compiles the full passes only (every pass one lane per target): the instantiation
 // for a scene whose tiles hold exactly kTBlock targets (a lattice at rest) is a few per cent faster
 // without the second copy of the body; the host picks per step from the tile statistics.
-template <bool SHARE, class Body>
+template <bool SHARE, int BLOCK = kTBlock, class Body>
 __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, Body&& body) {
   int tbase = 0;
-  for (; SHARE ? ntarg - tbase > kTBlock / 2 : tbase < ntarg; tbase += kTBlock) {
+  for (; SHARE ? ntarg - tbase > BLOCK / 2 : tbase < ntarg; tbase += BLOCK) {
     const int t = tbase + tperm;
     if (t < ntarg) body(std::false_type{}, t, 0, 1);
   }
   if constexpr (SHARE)
   while (tbase < ntarg) {
     const int rem = ntarg - tbase;
-    const int shift = rem > kTBlock / 4 ? 1 : (rem > kTBlock / 8 ? 2 : (rem > kTBlock / 16 ? 3 : 4));  // 16: one run per lane
+    const int shift = rem > BLOCK / 4 ? 1 : (rem > BLOCK / 8 ? 2 : (rem > BLOCK / 16 ? 3 : 4));  // 16: one run per lane
     const int t = tid >> shift;
     if (t < rem) body(std::true_type{}, tbase + t, tid & ((1 << shift) - 1), 1 << shift);
-    tbase += min(rem, kTBlock >> shift);
+    tbase += min(rem, BLOCK >> shift);
   }
 }
 
@@ -774,6 +787,11 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
         self_term = (me.x == me.x && me.y == me.y && me.z == me.z) ? 1.0f : 0.0f;
         const float two_hh = 2.0f * c.inv_hh;
         const float sx = two_hh * me.x, sy = two_hh * me.y, sz = two_hh * me.z, a0 = 1.0f + me.w;
+#ifdef DSL_PROBE_PAIR
+        const float px2 = sx * 1.01f, py2 = sy * 0.99f, pz2 = sz * 1.02f, pa2 = a0 - 0.01f;
+        float pacc2 = 0.f, pacc3 = 0.f;
+        unsigned int pmask2 = 0u;
+#endif
         // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
         auto sweep_run = [&](int ri, int rr) {
           int j, je;
@@ -793,6 +811,12 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
               mask_push(mask, q);
               if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
               else acc = __builtin_fmaf(q, q, acc);
+#ifdef DSL_PROBE_PAIR  // timing probe (r03): a second target's test on the same record -- what two targets per lane would cost
+              const float q2 = fma_clamp01(cnd.z, pz2, __builtin_fmaf(cnd.y, py2, __builtin_fmaf(cnd.x, px2, cnd.w + pa2)));
+              mask_push(pmask2, q2);
+              if (u & 1) pacc3 = __builtin_fmaf(q2, q2, pacc3);
+              else pacc2 = __builtin_fmaf(q2, q2, pacc2);
+#endif
             }
           };
           auto sweep_to = [&](int jend) {  // 8 candidates per trip while they last, then at most one block of 4
@@ -808,6 +832,10 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
           const int j32 = j + 32;
           sweep_to(min(je, j32));
           nmask[(size_t)ri * mstride + g] = mask;
+#ifdef DSL_PROBE_PAIR
+          nmask[(size_t)(kMaskHigh + ri) * mstride + g] = pmask2;  // (keeps the probe's second test alive)
+          pmask2 = 0u;
+#endif
           if (je > j32) {  // a second word for candidates 32-63 (rare: occupancy 8.3 +- 2 per cell once melted);
             mask = 0u;     // a run longer than 64 leaves garbage in it, its valid bit is clear
             sweep_to(je);
@@ -826,6 +854,9 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
           for (int ri = sub; ri < 9; ri += k) sweep_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
         }
         acc += acc1;
+#ifdef DSL_PROBE_PAIR
+        if (pacc2 + pacc3 == 12345.678f) acc += 1.0f;  // (keeps the probe's sums alive)
+#endif
       } else if (sub == 0) {
         const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
         for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
@@ -932,6 +963,245 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
       else sync_lds();
       sweep(m, Abuf[0], force_global);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// D (tiled), TWO TARGETS PER LANE (round 3; FAST arithmetic, single domain and slabs)
+//
+// The density sweep is bound by VALU issue, and a third of what it issues is not candidate tests: per-run set-up, loop
+// control, the wait for every record (profiles/r03_mfma_pipelined_experiment.md; a probe build that ran a SECOND test on
+// every record it read took 1.19 ms for twice the tests where the kernel takes 0.79 for once).  Two targets of the SAME
+// cell sweep the same nine runs, so a lane takes a pair of them: every record is read once and tested twice, every run is
+// set up once for two.  256-thread workgroups (a tile's 512 targets are 256 pairs), four per CU (39.6 KB of LDS each),
+// single-buffered.  A slot is two targets of one cell, or a cell's odd one out (its second test then runs on a target
+// that nothing can meet); TileMeta::pprefix is the slots' prefix over the tile's 16 interior rows.  Same records,
+// same q, same masks, same sums in the same order per target as k_density_tiled<.., false>: the results are the same bits.
+// ---------------------------------------------------------------------------------
+constexpr int kPBlock = 256;
+struct PairSlot {
+  int srow, lx, g, own;  // staged row and tile-local x cell of the slot's cell; global slot and LDS record of its first target
+  bool two;              // the slot holds two targets (g + 1, own + 1 is the second)
+};
+__device__ __forceinline__ PairSlot pair_slot(const TileMeta& m, int u) {
+  int ir = 0;  // largest interior row with pprefix[ir] <= u
+  ir += (u >= m.pprefix[ir + 8]) ? 8 : 0;
+  ir += (u >= m.pprefix[ir + 4]) ? 4 : 0;
+  ir += (u >= m.pprefix[ir + 2]) ? 2 : 0;
+  ir += (u >= m.pprefix[ir + 1]) ? 1 : 0;
+  const int4 w = m.trow[ir];
+  const int b1 = m.tprefix[ir], b2 = w.z & 0xffff, b3 = (int)((unsigned)w.z >> 16), b4 = w.w, b5 = m.tprefix[ir + 1];
+  const int n1 = (b2 - b1 + 1) >> 1, n2 = (b3 - b2 + 1) >> 1, n3 = (b4 - b3 + 1) >> 1;
+  int q = u - m.pprefix[ir];
+  int lx = 1, begin = b1, end = b2;
+  if (q >= n1) {
+    q -= n1, lx = 2, begin = b2, end = b3;
+    if (q >= n2) {
+      q -= n2, lx = 3, begin = b3, end = b4;
+      if (q >= n3) q -= n3, lx = 4, begin = b4, end = b5;
+    }
+  }
+  const int t0 = begin + 2 * q;
+  PairSlot r;
+  r.srow = (ir / kTB + 1) * kTH + (ir % kTB + 1);
+  r.lx = lx;
+  r.g = w.x + t0;
+  r.own = w.y + t0;
+  r.two = t0 + 1 < end;
+  return r;
+}
+
+template <bool SHARE>
+__global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+                                                             const int* __restrict__ n_tiles, const int* __restrict__ desc,
+                                                             const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
+                                                             float* __restrict__ rho, float* __restrict__ pterm,
+                                                             unsigned int* __restrict__ nmask, int mstride) {
+  __shared__ TileMeta metas[2];
+  __shared__ float4 A[kTCap];
+  const int tid = threadIdx.x;
+  if (c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
+  auto load4 = [&](int g, float4* o) {
+    o[0] = load4u(p.x + g);
+    o[1] = load4u(p.y + g);
+    o[2] = load4u(p.z + g);
+  };
+  auto load1 = [&](int g, float* o) {
+    o[0] = p.x[g];
+    o[1] = p.y[g];
+    o[2] = p.z[g];
+  };
+  // a tile's table: kMetaInts dwords, two per lane
+  auto meta_request = [&](int desc_index, int (&w)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * kPBlock;
+      w[k] = i < kMetaInts ? desc[(size_t)desc_index * kMetaInts + i] : 0;
+    }
+  };
+  auto meta_store = [&](TileMeta& m, const int (&w)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * kPBlock;
+      if (i < kMetaInts) reinterpret_cast<int*>(&m)[i] = w[k];
+    }
+  };
+  TileFeed feed(desc_of, *n_tiles);
+  int di = 0;
+  bool have = feed.pop(di);
+  if (!have) return;
+  {
+    int w[2];
+    meta_request(di, w);
+    meta_store(metas[0], w);
+  }
+  for (int cur = 0; have; cur ^= 1) {
+    TileMeta& m = metas[cur];
+    sync_lds();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
+    have = feed.pop(di);
+    int tw[2] = {0, 0};
+    if (have) meta_request(di, tw);
+    const bool ovf = m.overflow != 0;
+    if (!ovf) {
+      const float ox = __int_as_float(m.centre[0]), oy = __int_as_float(m.centre[1]), oz = __int_as_float(m.centre[2]);
+      auto store = [&](int slot, const float* o, bool real) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+        if (real) {
+          const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+          v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+        }
+        A[slot] = v;
+      };
+      // 36 rows x 14 quads = 504 quad slots on 256 lanes: two per lane, all six loads in flight together
+      StageRegs<3> sr0, sr1;
+      stage_issue<3>(m, load4, sr0, tid);
+      stage_issue<3>(m, load4, sr1, tid + kPBlock);
+      stage_commit<3>(m, sr0, load1, store, tid);
+      stage_commit<3>(m, sr1, load1, store, tid + kPBlock);
+    }
+    if (have) meta_store(metas[cur ^ 1], tw);
+    sync_lds();
+    const int nslots = m.pprefix[kTB * kTB];
+    for_each_target<SHARE, kPBlock>(nslots, tid, tid, [&](auto shared_c, int u, int sub, int k) {
+      constexpr bool SHARED = decltype(shared_c)::value;
+      const PairSlot ps = pair_slot(m, u);
+      const int srow = ps.srow, lx = ps.lx, g0 = ps.g;
+      const bool two = ps.two;
+      float acc[2] = {0.0f, 0.0f}, accb[2] = {0.0f, 0.0f}, self_term[2] = {1.0f, 1.0f};
+      unsigned int mvalid = 0u;
+      if (!ovf) {
+        const float4 me0 = A[ps.own];
+        float4 me1 = A[ps.own + (two ? 1 : 0)];
+        // a particle whose position has gone NaN (the reference produces such next to boundary particles)
+        // meets nobody, itself included: q is NaN, clamped to 0, for every candidate
+        self_term[0] = (me0.x == me0.x && me0.y == me0.y && me0.z == me0.z) ? 1.0f : 0.0f;
+        self_term[1] = (me1.x == me1.x && me1.y == me1.y && me1.z == me1.z) ? 1.0f : 0.0f;
+        const float two_hh = 2.0f * c.inv_hh;
+        const float sx0 = two_hh * me0.x, sy0 = two_hh * me0.y, sz0 = two_hh * me0.z, a00 = 1.0f + me0.w;
+        const float sx1 = two_hh * me1.x, sy1 = two_hh * me1.y, sz1 = two_hh * me1.z;
+        const float a01 = two ? 1.0f + me1.w : -1.0e30f;  // (an odd one out: its second test meets nobody)
+        // one x-run of candidates (row rr of the staged tile, the 3 cells around the slot's cell), both targets
+        auto sweep_run = [&](int ri, int rr) {
+          int j, je;
+          tile_run(m, rr, lx, j, je);
+          if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
+          unsigned int mask0 = 0u, mask1 = 0u;
+          auto test4 = [&](int jj) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const float4 cnd = A[jj + v];
+              const float q0 = fma_clamp01(cnd.z, sz0, __builtin_fmaf(cnd.y, sy0, __builtin_fmaf(cnd.x, sx0, cnd.w + a00)));
+              const float q1 = fma_clamp01(cnd.z, sz1, __builtin_fmaf(cnd.y, sy1, __builtin_fmaf(cnd.x, sx1, cnd.w + a01)));
+              mask_push(mask0, q0);
+              mask_push(mask1, q1);
+              if (v & 1) {
+                accb[0] = __builtin_fmaf(q0, q0, accb[0]);
+                accb[1] = __builtin_fmaf(q1, q1, accb[1]);
+              } else {
+                acc[0] = __builtin_fmaf(q0, q0, acc[0]);
+                acc[1] = __builtin_fmaf(q1, q1, acc[1]);
+              }
+            }
+          };
+          auto sweep_to = [&](int jend) {  // 8 candidates per trip while they last, then at most one block of 4
+            for (; j + 4 < jend; j += 8) {
+              test4(j);
+              test4(j + 4);
+            }
+            if (j < jend) {
+              test4(j);
+              j += 4;
+            }
+          };
+          const int j32 = j + 32;
+          sweep_to(min(je, j32));
+          nmask[(size_t)ri * mstride + g0] = mask0;
+          if (two) nmask[(size_t)ri * mstride + g0 + 1] = mask1;
+          if (je > j32) {  // a second word for candidates 32-63; a run longer than 64 leaves garbage in it, its valid bit is clear
+            mask0 = mask1 = 0u;
+            sweep_to(je);
+            nmask[(size_t)(kMaskHigh + ri) * mstride + g0] = mask0;
+            if (two) nmask[(size_t)(kMaskHigh + ri) * mstride + g0 + 1] = mask1;
+          }
+        };
+        if constexpr (!SHARED) {
+          int ri = 0;
+#pragma unroll 1
+          for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+            for (int dy = -1; dy <= 1; ++dy, ++ri) sweep_run(ri, srow + dz + dy);
+          }
+        } else {
+#pragma unroll 1
+          for (int ri = sub; ri < 9; ri += k) sweep_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
+        }
+        acc[0] += accb[0];
+        acc[1] += accb[1];
+      } else if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (e == 1 && !two) break;
+          const int g = g0 + e;
+          const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
+          float a = 0.0f;
+          for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+            if (j == g) return;
+            const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+            const float r2 = dist2<true>(dx, dy, dz);
+            if (r2 < c.hh) {
+              const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+              a = __builtin_fmaf(c.mass * c.A, q * q, a);
+            }
+          });
+          acc[e] = a;
+        }
+      }
+      if constexpr (SHARED) {
+        for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
+          acc[0] += __shfl_xor(acc[0], o, kWave);
+          acc[1] += __shfl_xor(acc[1], o, kWave);
+          mvalid |= __shfl_xor(mvalid, o, kWave);
+        }
+        if (sub != 0) return;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (e == 1 && !two) break;
+        const int g = g0 + e;
+        float a = acc[e];
+        if (!ovf) a = (a - self_term[e]) * (c.mass * c.A);  // the particle met itself once (q = 1)
+        nmask[(size_t)kMaskValid * mstride + g] = mvalid;
+        if (bnd.is(g)) {  // a boundary particle reads as density 0, P/rho^2 = 0/0 (Bnd, sph_device.hpp)
+          rho[g] = 0.0f;
+          pterm[g] = __uint_as_float(0x7fc00000u);
+          continue;
+        }
+        rho[g] = a;
+        // (an isolated particle's own term must be a harmless 0 rather than 0/0: see k_density_tiled)
+        const float pr = tait_eos<true>(c, a, c.eos_d0_grad);
+        pterm[g] = a > 0.0f ? dsl_div<true>(pr, a * a) : 0.0f;
+      }
+    });
   }
 }
 

@@ -107,7 +107,7 @@ def brute_force_step_f64(p, x, v, probe, near):
     return rho_p, x_new, v_new
 
 
-def fast_velocity_tolerance(p, steps):
+def fast_velocity_tolerance(p, steps, eps_rho=2.0e-6):
     """Absolute velocity tolerance (m/s) of DSL_MATH_FAST against the oracle after `steps` steps of a
     scene with the pressure force on.  Error model: FAST densities agree with the oracle to eps_rho ~ 2e-6
     (fma + expanded r^2 instead of separately rounded operations); the Tait EOS turns that into
@@ -116,6 +116,8 @@ def fast_velocity_tolerance(p, steps):
     Measured (tools/fast_errors.py, MI355X): 0.08-0.2 of this bound after 1 step, 0.03-0.07 after 10
     (errors of successive steps do not add coherently); after ~40 steps of a developed flow the two
     trajectories part for good (a neighbour crossing r = h one step apart), which is why parity is
-    checked over at most 10 steps.  Half the bound is asserted."""
+    checked over at most 10 steps.  Half the bound is asserted.  `eps_rho`: the density agreement the model starts
+    from -- 2e-6 on a jittered lattice; a developed flow (cells of 4 to 26 particles, tile-relative coordinates up to 3.5
+    cells) measures up to 5e-6 (tools/pair_diag.py), and its tests pass 6e-6."""
     cs2 = float(p.eos_w) / float(p.mass)
-    return 0.5 * float(p.eos_gamma) * 2.0e-6 * cs2 / float(p.h) * float(p.dt) * steps
+    return 0.5 * float(p.eos_gamma) * eps_rho * cs2 / float(p.h) * float(p.dt) * steps

@@ -20,9 +20,11 @@ def _engine(p):
 
 @pytest.fixture(scope="module")
 def melted():
-    """dam-break block of 20^3 particles advanced on the GPU (FAST) until the column has collapsed"""
+    """dam-break block of 20^3 particles advanced on the GPU until the column has collapsed.  Advanced in EXACT mode: that
+    trajectory is the oracle's, bit for bit, so the snapshot does not change whenever a FAST kernel rounds differently
+    (it used to be a FAST run, and every such change handed the tests below another flow to be calibrated on)"""
     from dieselfluid_amd import scenes
-    p, pos = scenes.dambreak_scene(20, math_mode=FAST)
+    p, pos = scenes.dambreak_scene(20, math_mode=EXACT)
     eng = _engine(p)
     eng.upload("positions", pos)
     eng.reset_forces()
@@ -69,9 +71,24 @@ def test_steps_from_a_developed_state_match_the_oracle(melted, math_mode, steps,
         assert np.array_equal(gv.view(np.uint32), ora.velocities().view(np.uint32))
         assert np.array_equal(gr.view(np.uint32), ora.densities().view(np.uint32))
     else:
-        assert helpers.rel_err(gx, ora.positions()) < tol_x
-        assert np.abs(gv.astype(np.float64) - ora.velocities()).max() < helpers.fast_velocity_tolerance(p, steps)
-        assert helpers.rel_err(gr, ora.densities()) < tol_rho
+        # Particles about to touch a wall are left out of the FAST comparison: the wall is a clamp + reflect, i.e. an EVENT,
+        # and a particle that crosses the plane one step earlier in one arithmetic than in the other loses its normal
+        # velocity a step apart (seen with particles 1e-5 from the x = 0 plane: 0.15 m/s and 1e-4 in x after 10 steps,
+        # identically for every FAST density kernel).  "About to": off the plane now, but within four times its own travel
+        # of it; particles resting ON a wall (most of a collapsed column lies on the floor) stay in.
+        ox = ora.positions()
+        speed = np.linalg.norm(v, axis=1)
+        reach = 4.0 * speed * float(p.dt) * steps + 1.0e-6
+        near = np.zeros(x.shape[0], dtype=bool)
+        for a in range(3):
+            lo, hi = x[:, a] - p.box_min[a], p.box_max[a] - x[:, a]
+            near |= ((lo > 0) & (lo < reach)) | ((hi > 0) & (hi < reach))
+        keep = ~near
+        assert keep.sum() > 0.75 * x.shape[0]
+        assert helpers.rel_err(gx[keep], ox[keep]) < tol_x
+        # (densities of a developed flow agree to 3e-6 .. 5e-6, velocities to 0.2 .. 0.6 of this bound: tools/pair_diag.py)
+        assert np.abs(gv[keep].astype(np.float64) - ora.velocities()[keep]).max() < helpers.fast_velocity_tolerance(p, steps, eps_rho=6.0e-6)
+        assert helpers.rel_err(gr[keep], ora.densities()[keep]) < tol_rho
     eng.close()
 
 

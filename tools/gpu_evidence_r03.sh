@@ -26,7 +26,7 @@ profile() {  # profile <tag> <steps> <bench args...>   (bench.py's exact / devel
     rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/prof_${tag}_pmc$i -- $cmd --steps $steps --warmup 1 > /dev/null 2> $out/${tag}_pmc$i.err || echo "$tag pmc set $i failed"
     dirs="$dirs /tmp/prof_${tag}_pmc$i"
   done
-  python3 $R/tools/pmc_summary.py $dirs --filter tiled > $out/${tag}_pmc.md
+  python3 $R/tools/pmc_summary.py $dirs --filter tiled,k_density_pair > $out/${tag}_pmc.md
   echo "$tag pmc done"
 }
 profile wcsph16m 3

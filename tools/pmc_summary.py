@@ -21,7 +21,7 @@ def main():
     for f in sorted(files):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if flt and flt not in name:
+            if flt and not any(f_ in name for f_ in flt.split(",")):  # (--filter a,b: any of the substrings)
                 continue
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
