@@ -370,8 +370,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
                          h->scan_status, h->scan_ticket, h->nscan, h->dstats);
       return;
     }
-    hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(kBlock), 0, h->stream, h->block_sums, h->nscan, h->dstats,
+    hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums, h->dstats,
                        !h->lsh ? h->n_tiles : nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
                        h->cell_start, h->dstats);

@@ -123,8 +123,15 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total)
 }
 
 // phase 1: one sum per 4096-cell tile
-__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ count, int* __restrict__ block_sums) {
+// (block 0 also clears the small counters of the later kernels -- the fullest-cell statistic of phase 3, the tile-list
+// lengths -- which used to be the job of a one-block middle phase; phase 3 now adds up its predecessors' sums itself)
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ count, int* __restrict__ block_sums,
+                                                       DevStats* stats, int* __restrict__ n_tiles) {
   __shared__ int lds[kBlock / kWave];
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) stats->max_cell_count = 0;
+    if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
+  }
   const int4* src = reinterpret_cast<const int4*>(count + (size_t)blockIdx.x * kScanTile);
   int s = 0;
 #pragma unroll
@@ -137,26 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ co
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// phase 2: exclusive scan of the tile sums in place (single block).  Runs between the histogram
-// and everything that follows it, so it also clears the small counters of the later kernels
-// (the fullest-cell statistic of phase 3, the tile-list lengths) instead of two more memsets.
-__global__ __launch_bounds__(kBlock) void k_scan_top(int* __restrict__ block_sums, int nb, DevStats* stats,
-                                                     int* __restrict__ n_tiles) {
-  __shared__ int lds[kBlock / kWave];
-  if (threadIdx.x == 0) stats->max_cell_count = 0;
-  if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
-  int carry = 0;
-  for (int base = 0; base < nb; base += kBlock) {
-    const int idx = base + threadIdx.x;
-    const int v = idx < nb ? block_sums[idx] : 0;
-    int total;
-    const int ex = block_exclusive_scan(v, lds, total);
-    if (idx < nb) block_sums[idx] = carry + ex;
-    carry += total;
-  }
-}
-
-// phase 3: exclusive scan inside each tile + tile offset; also tracks the fullest cell
+// phase 2: exclusive scan inside each tile + tile offset; also tracks the fullest cell
 // (the histogram is left zeroed for the next build: saves that build a memset launch)
 __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
                                                        const int* __restrict__ block_sums,
@@ -164,7 +152,16 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
   __shared__ int lds[kBlock / kWave];
   int4* src = reinterpret_cast<int4*>(count + (size_t)blockIdx.x * kScanTile);
   int4* dst = reinterpret_cast<int4*>(cell_start + (size_t)blockIdx.x * kScanTile);
-  int carry = block_sums[blockIdx.x];
+  // the tile's offset: the sum of the tile sums in front of it (at most a few thousand ints, L2-resident: cheaper than
+  // the one-block launch that used to turn them into a prefix)
+  int carry = 0;
+  {
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += block_sums[i];
+    int total;
+    block_exclusive_scan(part, lds, total);
+    carry = total;
+  }
   int mx = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
