@@ -560,6 +560,19 @@ func (e *Engine) PCISPHErrorWord(devWord unsafe.Pointer, store bool) error {
 	return e.ck(C.dsl_pcisph_error_word(e.h, (*C.uint32_t)(devWord), s))
 }
 
+// PCISPHSetBinning: -1 never, 0 automatic (default), 1 always -- whether the DensityF query points (the predictor's
+// positions, which the reference never re-synchronises: pcisph_darwin.go:28-41) are sorted into grid cells of their own.
+func (e *Engine) PCISPHSetBinning(mode int) error {
+	return e.ck(C.dsl_pcisph_set_binning(e.h, C.int(mode)))
+}
+
+// PCISPHBinning: the mode, and whether the next correction iteration will sort its queries.
+func (e *Engine) PCISPHBinning() (mode int, active bool, err error) {
+	var m, a C.int
+	err = e.ck(C.dsl_pcisph_get_binning(e.h, &m, &a))
+	return int(m), a != 0, err
+}
+
 // NewCommAll: one process, several devices (ncclCommInitAll); NewEngines wraps it together with the handles.
 func NewCommAll(devices []int) ([]*Comm, error) {
 	n := len(devices)

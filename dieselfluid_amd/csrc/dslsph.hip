@@ -76,6 +76,19 @@ struct dsl_handle {
   float* pci[2][6] = {};
   float *rho = nullptr, *pterm = nullptr, *press = nullptr, *scratch1 = nullptr;
   float* gterm[3] = {};  // PCISPH: cached pressure-gradient force term
+  // PCISPH with the DensityF query points in bins of their own (kernels_sph.hpp: k_pci_predict_bin): the histogram over
+  // the particles' grid cells, its prefix, the scan's tile sums, one record per query, and the 512 drift counters the
+  // un-binned kernels keep.  pci_bin_mode: 0 = the library switches when 1 % of the predicted positions have left their
+  // particle's tile (looked at every kPciDriftPeriod steps; a one-way latch until the next dsl_pcisph_begin), 1 = always,
+  // -1 = never (dsl_pcisph_set_binning; DSL_PCI_BINNED presets it)
+  int pci_bin_mode = 0;
+  bool pci_binned = false;
+  bool pci_qtiled = true;  // FAST: sweep the binned queries tile by tile out of LDS (DSL_PCI_QTILED=0: the global-memory sweep)
+  int64_t pci_steps = 0;  // completed steps since dsl_pcisph_begin
+  int *qcount = nullptr, *qstart = nullptr, *qsums = nullptr;
+  int *qtiles = nullptr, *n_qtiles = nullptr, *qtile_desc = nullptr;  // FAST: the tiles that hold queries and their tables
+  float4* qrec = nullptr;
+  unsigned int* pci_drift = nullptr;
   float* xsph[3] = {};   // build-defined XSPH correction of the current step (PCISPH path)
   unsigned int* nmask = nullptr;  // FAST: per-particle in-range masks from the density sweep (kMaskWords x cap)
   bool masks_valid = false;
@@ -357,11 +370,14 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   }
   h->sort_scratch_dirty = true;
   const bool onepass = h->scan_onepass;
+  // PCISPH: "a particle lies outside the grid's bounds" (dcounter[4]; k_pci_predict_bin finishes far-away queries on the
+  // spot when none does)
+  if (h->pci_active) HIP_TRY(h, hipMemsetAsync(h->dcounter + 4, 0, sizeof(int), h->stream));
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                        ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
                        onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
-                       ordered ? h->cell_keys : nullptr, h->dcounter + 3);
+                       ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->pci_active ? h->dcounter + 4 : nullptr);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
@@ -433,7 +449,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
                          h->unordered, h->ncell_pad / 32, h->dcounter + 3);
       // the tables of the non-empty tiles, once per build for every kernel that sweeps tiles
       hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, h->c, h->tg,
-                         h->cell_start, h->tiles, h->n_tiles, h->tile_desc);
+                         h->cell_start, h->cell_start, h->tiles, h->n_tiles, h->tile_desc);
     });
     if (rc) return rc;
     h->sort_scratch_dirty = false;  // k_scan_apply and k_tile_list are queued: they leave both arrays clean
@@ -744,6 +760,14 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->cell_count);
   (void)hipFree(h->cell_start);
   (void)hipFree(h->block_sums);
+  (void)hipFree(h->qcount);
+  (void)hipFree(h->qstart);
+  (void)hipFree(h->qsums);
+  (void)hipFree(h->qrec);
+  (void)hipFree(h->qtiles);
+  (void)hipFree(h->n_qtiles);
+  (void)hipFree(h->qtile_desc);
+  (void)hipFree(h->pci_drift);
   (void)hipFree(h->scan_status);
   (void)hipFree(h->scan_ticket);
   (void)hipFree(h->stage);
@@ -783,6 +807,25 @@ int alloc_pci(dsl_handle* h) {
     for (int k = 0; k < 6; ++k)
       if (!h->pci[w][k])
         if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
+  if (!h->pci_drift)
+    if (int rc = dev_alloc(h, &h->pci_drift, (size_t)512)) return rc;
+  return DSL_OK;
+}
+
+bool pci_tiled(const dsl_handle* h);
+// the query bins are allocated when the binned form is first used (every array zero-filled by dev_alloc; k_scan_apply
+// leaves the histogram clean behind every use)
+int alloc_query_bins(dsl_handle* h) {
+  int rc = DSL_OK;
+  if (!h->qcount && (rc = dev_alloc(h, &h->qcount, (size_t)h->ncell_pad))) return rc;
+  if (!h->qstart && (rc = dev_alloc(h, &h->qstart, (size_t)h->ncell_pad))) return rc;
+  if (!h->qsums && (rc = dev_alloc(h, &h->qsums, (size_t)h->nscan))) return rc;
+  if (!h->qrec && (rc = dev_alloc(h, &h->qrec, (size_t)h->cap))) return rc;
+  if (pci_tiled(h)) {  // the LDS-tiled sweep over query tiles (kernels_tiled.hpp: k_pci_density_qtiled)
+    if (!h->qtiles && (rc = dev_alloc(h, &h->qtiles, (size_t)h->tg.ntiles))) return rc;
+    if (!h->n_qtiles && (rc = dev_alloc(h, &h->n_qtiles, (size_t)8))) return rc;
+    if (!h->qtile_desc && (rc = dev_alloc(h, &h->qtile_desc, (size_t)std::min(h->tg.ntiles, h->cap) * kMetaInts))) return rc;
+  }
   return DSL_OK;
 }
 
@@ -887,7 +930,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->scan_status, (size_t)h->nscan)) ||
       (rc = dev_alloc(h, &h->scan_ticket, 1)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
-      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 4)) || (rc = dev_alloc(h, &h->dn, 16)) ||
+      (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 8)) || (rc = dev_alloc(h, &h->dn, 16)) ||
       (rc = dev_alloc(h, &h->pack_counts, (size_t)4 * ((n + kPackChunk - 1) / kPackChunk))))
     return bail(rc);
   // the sort keeps these two clean between builds (k_scan_apply, k_tile_list)
@@ -922,6 +965,11 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
   if (const char* e = std::getenv("DSL_SCAN_ONEPASS")) h->scan_onepass = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_DENSITY_PAIR")) h->density_pair = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DSL_PCI_QTILED")) h->pci_qtiled = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DSL_PCI_BINNED")) {  // -1 never, 0 automatic, 1 always (dsl_pcisph_set_binning)
+    const int m = std::atoi(e);
+    h->pci_bin_mode = m < 0 ? -1 : (m > 0 ? 1 : 0);
+  }
   if (const char* e = std::getenv("DSL_PERSISTENT_BLOCKS")) h->max_persistent_blocks = std::atoi(e);
   {  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
     int bx = 8, by = 4, bz = 4;
@@ -1473,10 +1521,35 @@ int dsl_pcisph_begin(dsl_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(h->pci[h->cur_pci][k], h->pv[h->cur_pv][k], n * sizeof(float), hipMemcpyDeviceToDevice,
                               h->stream));
   h->pci_active = true;
+  // the predicted positions are the particles' again: the un-binned sweeps are the fast ones until they drift apart
+  if (h->pci_steps != 0) HIP_TRY(h, hipMemsetAsync(h->pci_drift, 0, 512 * sizeof(unsigned int), h->stream));
+  h->pci_steps = 0;
+  h->pci_binned = false;
   return DSL_OK;
 }
 
 namespace {
+constexpr int kPciDriftPeriod = 8;         // steps between two looks at the drift counters
+constexpr double kPciDriftFraction = 0.01;  // of the predicted positions outside their particle's tile: bin the queries
+
+// Every kPciDriftPeriod steps: how many DensityF query points have left their particle's tile since the last look
+// (counted by the un-binned kernels).  The one host read-back of the PCISPH step -- 2 KB, at a step boundary that is
+// a function of the step count alone, so a run's arithmetic does not depend on how its steps were grouped into calls.
+int pci_drift_check(dsl_handle* h) {
+  if (h->pci_bin_mode != 0 || h->pci_binned || h->lsh || h->pci_steps == 0 || h->pci_steps % kPciDriftPeriod != 0) return DSL_OK;
+  unsigned int cnt[512];
+  HIP_TRY(h, hipMemcpyAsync(cnt, h->pci_drift, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  unsigned long long left = 0, all = 0;
+  for (int k = 0; k < 256; ++k) {
+    left += cnt[k];
+    all += cnt[256 + k];
+  }
+  if (all != 0 && (double)left > kPciDriftFraction * (double)all) h->pci_binned = true;
+  else HIP_TRY(h, hipMemsetAsync(h->pci_drift, 0, sizeof(cnt), h->stream));
+  return DSL_OK;
+}
+
 // FAST mode: LDS-tiled sweeps; the gradient term (a function of x and rho only,
 // field_types.go:39-42) is identical in every correction iteration, so it is swept once
 // and re-added.  The running-mass viscosity recurrence for m != 1 needs the branching kernel.
@@ -1488,6 +1561,7 @@ bool pci_extra_terms(const dsl_handle* h) { return h->c.xsph_eps != 0.0f || h->c
 // NN, DensityAll, ViscousAll (pcisph_darwin.go:43-45) and the loop set-up
 int pci_begin_step(dsl_handle* h) {
   const DevConsts& c = h->c;
+  if (int rc = pci_drift_check(h)) return rc;
   if (int rc = build_grid(h, false)) return rc;
   if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
   if (int rc = materialise_forces(h)) return rc;
@@ -1530,19 +1604,59 @@ int pci_iterate(dsl_handle* h) {
   CSoa3 cF{F.x, F.y, F.z};
   Soa3 pp = mpcip(h), pvv = mpciv(h);
   const bool tiled = pci_tiled(h);
+  CSoa3 cpp{pp.x, pp.y, pp.z};
+  if (!h->lsh && (h->pci_bin_mode > 0 || (h->pci_bin_mode == 0 && h->pci_binned))) {
+    // the query points have left their particles (or the host asked for it): counting sort of the queries by their own
+    // cells, then the sweep in that order (kernels_sph.hpp: k_pci_predict_bin)
+    if (int rc = alloc_query_bins(h)) return rc;
+    CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
+    int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
+      if (tiled)
+        hipLaunchKernelGGL((k_pci_predict_bin<false, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
+                           h->qcount, h->rank, h->n_qtiles, h->pci_drift, h->dcounter + 4, h->press, h->dstats);
+      else
+        by_math(h, [&](auto fast) {
+          hipLaunchKernelGGL((k_pci_predict_bin<true, false, decltype(fast)::value>), g, b, 0, h->stream, c, bnd_of(h), p, pp,
+                             pvv, cG, F, h->qcount, h->rank, nullptr, h->pci_drift, h->dcounter + 4, h->press, h->dstats);
+        });
+      hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, nullptr, nullptr);
+      hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, h->qstart, nullptr);
+      hipLaunchKernelGGL(k_pci_query_scatter, g, b, 0, h->stream, c, cpp, h->rank, h->qstart, h->qrec, h->dstats);
+      if (tiled && h->pci_qtiled) {  // the tiles that hold queries, and their tables
+        hipLaunchKernelGGL(k_qtile_list, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->qstart,
+                           h->qtiles, h->n_qtiles, h->dstats);
+        hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, c, h->tg,
+                           h->cell_start, h->qstart, h->qtiles, h->n_qtiles, h->qtile_desc);
+      }
+    });
+    if (rc) return rc;
+    rc = timed(h, DSL_K_PCI_DENSITY, [&] {
+      if (tiled && h->pci_qtiled) {
+        hipLaunchKernelGGL(k_pci_density_qtiled, dim3(persistent_grid(h, 2)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                           h->n_qtiles, h->qtile_desc, h->cell_start, p, h->qrec, h->press, h->dstats);
+        return;
+      }
+      by_math(h, [&](auto fast) {
+        hipLaunchKernelGGL((k_pci_density_binned<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), p, h->qrec,
+                           h->qstart, h->press, h->dstats);
+      });
+    });
+    if (rc) return rc;
+    return tiled ? DSL_OK : gradient_pass(h, 1);  // (tiled: F += the cached term went with the predictor)
+  }
   if (tiled) {  // predict, DensityF + pressure, F += cached gradient term: one launch (kernels_tiled.hpp)
     CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
     return timed(h, DSL_K_PCI_DENSITY, [&] {
       hipLaunchKernelGGL(k_pci_density_tiled, dim3(persistent_grid(h, 4)), dim3(kTBlock), 0, h->stream, c, h->tg,
                          h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), p, pp, pvv, cG, F, h->press,
-                         h->dstats);
+                         h->pci_drift, h->dstats);
     });
   }
   int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
-    hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, bnd_of(h), cF, pp, pvv, h->dstats);
+    hipLaunchKernelGGL(k_pci_predict, g, b, 0, h->stream, c, bnd_of(h), p, cF, pp, pvv, h->lsh ? nullptr : h->pci_drift,
+                       h->dstats);
   });
   if (rc) return rc;
-  CSoa3 cpp{pp.x, pp.y, pp.z};
   rc = timed(h, DSL_K_PCI_DENSITY, [&] {
     by_math(h, [&](auto fast) {
       hipLaunchKernelGGL((k_pci_density<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), bnd_of(h), p, cpp,
@@ -1562,6 +1676,7 @@ int pci_check(dsl_handle* h) {                   // :95-98
 int pci_end_step(dsl_handle* h) {                // Update :101 (positions advect with v + XSPH)
   if (int rc = update_pass(h, pci_extra_terms(h))) return rc;
   h->steps++;
+  h->pci_steps++;
   return DSL_OK;
 }
 }  // namespace
@@ -1603,6 +1718,21 @@ int dsl_pcisph_error_word(dsl_handle* h, uint32_t* dev_word, int store) {
   uint32_t* mine = &h->dstats->pci_cur_err_bits;
   HIP_TRY(h, hipMemcpyAsync(store ? mine : dev_word, store ? dev_word : mine, sizeof(uint32_t), hipMemcpyDeviceToDevice,
                             h->stream));
+  return DSL_OK;
+}
+
+int dsl_pcisph_set_binning(dsl_handle* h, int mode) {
+  CHECK_HANDLE(h);
+  if (mode < -1 || mode > 1) return fail(h, DSL_ERR_INVALID, "dsl_pcisph_set_binning: mode is -1 (never), 0 (automatic) or 1 (always)");
+  if (mode > 0 && h->lsh) return fail(h, DSL_ERR_UNSUPPORTED, "dsl_pcisph_set_binning: lsh_ref candidates do not come from grid cells");
+  h->pci_bin_mode = mode;
+  return DSL_OK;
+}
+
+int dsl_pcisph_get_binning(dsl_handle* h, int* mode, int* active) {
+  CHECK_HANDLE(h);
+  if (mode) *mode = h->pci_bin_mode;
+  if (active) *active = (!h->lsh && (h->pci_bin_mode > 0 || (h->pci_bin_mode == 0 && h->pci_binned))) ? 1 : 0;
   return DSL_OK;
 }
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
                                                       int* __restrict__ rank, int* __restrict__ cell_count,
                                                       unsigned int* __restrict__ unordered, DevStats* stats,
                                                       int* __restrict__ n_tiles, int* __restrict__ cell_keys,
-                                                      int* __restrict__ overfull) {
+                                                      int* __restrict__ overfull, int* __restrict__ off_grid) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   // the small counters of the later kernels of this build (the fullest-cell statistic of the scan, the tile-list
   // lengths): cleared here, at the head of the build, when the one-launch scan is in use (stats != nullptr)
@@ -63,6 +63,17 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   if (i < n) {
     cell = sort_cell(c, px[i], py[i], pz[i]);
     if (ids) id = ids[i];
+    // PCISPH (off_grid != nullptr, cleared by the host in front of this launch): does any particle lie outside the
+    // grid's bounds, clamped into an outermost cell by the cell rule?  (false for NaN: that particle is nobody's neighbour)
+    if (off_grid != nullptr) {
+      bool off = false;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float f = floorf(((a == 0 ? px[i] : (a == 1 ? py[i] : pz[i])) - c.gmin[a]) * c.inv_cell);
+        off |= f < 0.0f || f >= (float)c.dims[a];
+      }
+      if (off) *off_grid = 1;  // (benign race: every writer stores 1)
+    }
   }
   const int prev = __shfl_up(cell, 1, kWave), prev_id = __shfl_up(id, 1, kWave);
   const bool head = (lane == 0) || (cell != prev);
@@ -128,7 +139,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total)
 __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ count, int* __restrict__ block_sums,
                                                        DevStats* stats, int* __restrict__ n_tiles) {
   __shared__ int lds[kBlock / kWave];
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && stats != nullptr) {  // (stats == nullptr: a scan that is not the particles' build -- PCISPH query bins)
     if (threadIdx.x == 0) stats->max_cell_count = 0;
     if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
   }
@@ -183,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
   for (int off = kWave / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, kWave));
   // read first: almost every wave finds its maximum already recorded, and thousands of atomics on
   // one address would serialise
-  if ((threadIdx.x & (kWave - 1)) == 0 && mx > 0 &&
+  if (stats != nullptr && (threadIdx.x & (kWave - 1)) == 0 && mx > 0 &&
       mx > __hip_atomic_load(&stats->max_cell_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&stats->max_cell_count, mx);
 }
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_onepass(int* __restrict__ count
     dst[k * kBlock + threadIdx.x] = o;
   }
   for (int off = kWave / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, kWave));
-  if ((threadIdx.x & (kWave - 1)) == 0 && mx > 0 &&
+  if (stats != nullptr && (threadIdx.x & (kWave - 1)) == 0 && mx > 0 &&
       mx > __hip_atomic_load(&stats->max_cell_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
     atomicMax(&stats->max_cell_count, mx);
 }

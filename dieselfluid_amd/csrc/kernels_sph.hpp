@@ -525,21 +525,30 @@ __global__ __launch_bounds__(kBlock) void k_field_interpolate(DevConsts c, Neigh
 // ---------------------------------------------------------------------------------
 
 // predict :57-73 -- _vel += (F/m) dt ; _pos += _vel dt (state persists across steps)
-__global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, Bnd bnd, CSoa3 f, Soa3 pp, Soa3 pv,
-                                                        const DevStats* stats) {
+__device__ __forceinline__ bool pci_left_tile(const DevConsts& c, float x, float y, float z, float qx, float qy, float qz);
+__device__ __forceinline__ void pci_drift_add(unsigned int* __restrict__ drift, unsigned int n_out, unsigned int n_all);
+// (`drift`: how many predicted positions have left their particle's tile, see k_pci_predict_bin; nullptr in LSH mode)
+__global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, Bnd bnd, CSoa3 p, CSoa3 f, Soa3 pp, Soa3 pv,
+                                                        unsigned int* __restrict__ drift, const DevStats* stats) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c) || bnd.is(i)) return;  // the predictor loops over N() particles (pcisph_darwin.go:57-73)
-  const float ax = f.x[i] * c.inv_mass, ay = f.y[i] * c.inv_mass, az = f.z[i] * c.inv_mass;
-  const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
-  const float tvx = pv.x[i] + dvx, tvy = pv.y[i] + dvy, tvz = pv.z[i] + dvz;
-  const float dpx = tvx * c.dt, dpy = tvy * c.dt, dpz = tvz * c.dt;
-  pp.x[i] += dpx;
-  pp.y[i] += dpy;
-  pp.z[i] += dpz;
-  pv.x[i] = tvx;
-  pv.y[i] = tvy;
-  pv.z[i] = tvz;
+  bool mine = false, left = false;
+  if (i < live_n(c) && !bnd.is(i)) {  // the predictor loops over N() particles (pcisph_darwin.go:57-73)
+    const float ax = f.x[i] * c.inv_mass, ay = f.y[i] * c.inv_mass, az = f.z[i] * c.inv_mass;
+    const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
+    const float tvx = pv.x[i] + dvx, tvy = pv.y[i] + dvy, tvz = pv.z[i] + dvz;
+    const float dpx = tvx * c.dt, dpy = tvy * c.dt, dpz = tvz * c.dt;
+    const float qx = pp.x[i] + dpx, qy = pp.y[i] + dpy, qz = pp.z[i] + dpz;
+    pp.x[i] = qx;
+    pp.y[i] = qy;
+    pp.z[i] = qz;
+    pv.x[i] = tvx;
+    pv.y[i] = tvy;
+    pv.z[i] = tvz;
+    mine = true;
+    if (drift != nullptr) left = pci_left_tile(c, p.x[i], p.y[i], p.z[i], qx, qy, qz);
+  }
+  if (drift != nullptr) pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
 }
 
 // DF + pressure accumulate :76-92 -- SPHField.DensityF (sph_field.go:137-152): starts at
@@ -575,6 +584,168 @@ __global__ __launch_bounds__(kBlock) void k_pci_density(DevConsts c, Neigh nb, B
     press[i] += dp;
     // slab mode: a ghost's predicted density is meaningless (it sees half a neighbourhood) and must
     // not decide the iteration's error
+    if (slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
+  }
+  wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
+}
+
+// ---------------------------------------------------------------------------------
+// DensityF with the QUERY points binned (round 3).  The reference never brings its predictor state back to the
+// particles (pcisph_darwin.go:28-41: `_pos`, `_vel` are seeded once and advanced four times per step), so DensityF's
+// query points -- the predicted positions -- leave their particles behind: by step 50 of the 4M scene the median
+// distance is 0.27 h, by step 200 2.8 h, by step 600 15 h.  A sweep launched in the PARTICLES' slot order then has 64
+// lanes looking at 64 unrelated places (12.8 ms per iteration at step 600 where the first steps take 0.22).  Here the
+// queries get a counting sort of their own, by the cell of the query point in the particles' grid, every correction
+// iteration: predict + cell + rank (k_pci_predict_bin), the prefix scan of the build (k_scan_sums / k_scan_apply on
+// the query histogram), one record per query in cell order (k_pci_query_scatter), and the sweep in THAT order
+// (k_pci_density_binned): neighbouring lanes read the same candidates again.  Per query the candidates, their order and
+// the arithmetic are those of k_pci_density, so DSL_MATH_EXACT stays bit for bit the oracle's; the order of the queries
+// inside a cell comes from atomics and does not matter (a query's sum does not depend on the others).
+// ---------------------------------------------------------------------------------
+// `drift` is 512 counters: [w & 255] += queries of wave w whose tile is not their particle's, [256 + (w & 255)] += queries
+// of wave w; the host looks at them every few steps and switches the solver to the binned form for good.
+__device__ __forceinline__ bool pci_left_tile(const DevConsts& c, float x, float y, float z, float qx, float qy, float qz) {
+  bool out = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float pa = a == 0 ? x : (a == 1 ? y : z), qa = a == 0 ? qx : (a == 1 ? qy : qz);
+    out |= (cell_coord(pa, c.gmin[a], c.inv_cell, c.dims[a]) / kTB) != (cell_coord(qa, c.gmin[a], c.inv_cell, c.dims[a]) / kTB);
+  }
+  return out;
+}
+__device__ __forceinline__ void pci_drift_add(unsigned int* __restrict__ drift, unsigned int n_out, unsigned int n_all) {
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    n_out += __shfl_xor(n_out, off, kWave);
+    n_all += __shfl_xor(n_all, off, kWave);
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && n_all != 0u) {
+    const int slot = (blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave)) & 255;
+    if (n_out != 0u) atomicAdd(&drift[slot], n_out);
+    atomicAdd(&drift[256 + slot], n_all);
+  }
+}
+
+// predict (:57-73) for every particle the un-binned path would predict -- GHOSTS: every live fluid slot (the passes of
+// the per-pass path), otherwise owned slots only (k_pci_density_tiled) -- then, ADD_G: F += the cached gradient term
+// (:93, k_pci_density_tiled's tail), and the query's cell and its rank inside that cell.  Equal-cell runs of consecutive
+// lanes share one atomic (k_cell_rank's ballot trick: early in a run every query still sits in its particle's cell).
+// A query further than h outside the grid's bounds has no neighbour -- provided every particle lies inside them, which the
+// build checks (k_cell_rank: `off_grid`; the walls keep particles in the box, but nothing obliges a host to put the
+// grid around the box).  Such a query is finished here (density = W0, :76-92 on that value) instead of being clamped
+// into the grid's outermost cells with thousands of others: the predictor knows no walls, and by step 1500 of the 4M
+// scene four queries out of five are below the floor.
+template <bool GHOSTS, bool ADD_G, bool FAST>
+__global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd, CSoa3 p, Soa3 pp, Soa3 pv, CSoa3 gterm,
+                                                            Soa3 frc, int* __restrict__ qcount, int* __restrict__ qrank,
+                                                            int* __restrict__ n_qtiles, unsigned int* __restrict__ drift,
+                                                            const int* __restrict__ off_grid, float* __restrict__ press,
+                                                            DevStats* stats) {
+  if (stats->pci_done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i == 0 && n_qtiles != nullptr) *n_qtiles = 0;  // the length of this iteration's query-tile list (k_qtile_list)
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool all_inside = *off_grid == 0;
+  int cell = -1;
+  bool left = false, mine = false;
+  unsigned int err_bits = 0u;
+  if (i < live_n(c) && !bnd.is(i) && (GHOSTS || slab_owned(c, p.x[i], p.y[i], p.z[i]))) {
+    const float fx = frc.x[i], fy = frc.y[i], fz = frc.z[i];
+    const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
+    const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
+    const float tvx = pv.x[i] + dvx, tvy = pv.y[i] + dvy, tvz = pv.z[i] + dvz;
+    const float dpx = tvx * c.dt, dpy = tvy * c.dt, dpz = tvz * c.dt;
+    const float qx = pp.x[i] + dpx, qy = pp.y[i] + dpy, qz = pp.z[i] + dpz;
+    pp.x[i] = qx;
+    pp.y[i] = qy;
+    pp.z[i] = qz;
+    pv.x[i] = tvx;
+    pv.y[i] = tvy;
+    pv.z[i] = tvz;
+    if constexpr (ADD_G) {
+      frc.x[i] = fx + gterm.x[i];
+      frc.y[i] = fy + gterm.y[i];
+      frc.z[i] = fz + gterm.z[i];
+    }
+    mine = true;
+    left = pci_left_tile(c, p.x[i], p.y[i], p.z[i], qx, qy, qz);
+    bool far = false;
+    if (all_inside) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float f = ((a == 0 ? qx : (a == 1 ? qy : qz)) - c.gmin[a]) * c.inv_cell;  // in cells (a cell is h wide)
+        far |= f < -1.01f || f > (float)c.dims[a] + 1.01f;
+      }
+    }
+    if (far) {
+      const float density_error = c.W0 - c.ref_density;
+      const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
+      press[i] += density_error * c.delta;
+      if (!GHOSTS || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
+    } else {
+      cell = cell_of(c, qx, qy, qz);
+    }
+  }
+  const int prev = __shfl_up(cell, 1, kWave);
+  const bool head = (lane == 0) || (cell != prev);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long le = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+  const int head_lane = 63 - __builtin_clzll(le);
+  const unsigned long long above = (head_lane == 63) ? 0ull : (heads & ~((2ull << head_lane) - 1ull));
+  const int next = above ? __builtin_ctzll(above) : kWave;
+  int base = 0;
+  if (lane == head_lane && cell >= 0) base = atomicAdd(&qcount[cell], next - head_lane);
+  base = __shfl(base, head_lane, kWave);
+  if (i < live_n(c)) qrank[i] = cell >= 0 ? base + (lane - head_lane) : -1;
+  pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
+  wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
+}
+
+// one record per query, in the order of the queries' cells: the predicted position and the particle's slot
+__global__ __launch_bounds__(kBlock) void k_pci_query_scatter(DevConsts c, CSoa3 pp, const int* __restrict__ qrank,
+                                                              const int* __restrict__ qstart, float4* __restrict__ qrec,
+                                                              const DevStats* stats) {
+  if (stats->pci_done) return;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= live_n(c)) return;
+  const int r = qrank[i];
+  if (r < 0) return;
+  const float qx = pp.x[i], qy = pp.y[i], qz = pp.z[i];
+  qrec[qstart[cell_of(c, qx, qy, qz)] + r] = make_float4(qx, qy, qz, __int_as_float(i));
+}
+
+// DF + pressure accumulate :76-92 for query record k (k_pci_density's body; the query comes from its record)
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_pci_density_binned(DevConsts c, Neigh nb, CSoa3 p, const float4* __restrict__ qrec,
+                                                               const int* __restrict__ qstart, float* __restrict__ press,
+                                                               DevStats* stats) {
+  if (stats->pci_done) return;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  unsigned int err_bits = 0u;
+  if (k < qstart[c.ncell]) {
+    const float4 rec = qrec[k];
+    const int i = __float_as_int(rec.w);
+    const float xi = rec.x, yi = rec.y, zi = rec.z;
+    float density = c.W0;
+    for_each_grid_candidate(c, nb.cell_start, xi, yi, zi, [&](int j) {
+      const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+      const float r2 = dist2<FAST>(dx, dy, dz);
+      if constexpr (FAST) {
+        if (r2 < c.hh) {
+          const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+          density = __builtin_fmaf(c.mass * c.A, q * q, density);
+        }
+      } else {
+        const float dist = dsl_sqrt<false>(r2);
+        if (in_support(c, nb, dist)) {
+          const float w = kern_F<false>(c, dist);
+          density += c.mass * w;
+        }
+      }
+    });
+    const float density_error = density - c.ref_density;
+    const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
+    const float dp = density_error * c.delta;
+    press[i] += dp;
     if (slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
   }
   wave_atomic_max(&stats->pci_cur_err_bits, err_bits);

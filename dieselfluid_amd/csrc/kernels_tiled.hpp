@@ -236,7 +236,11 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
 // One wave per non-empty tile (tile list 0): the tile's table, written where the sweeping kernels
 // pick it up.  ~31k tiles x 1.5 KB at 16M particles.  Lane r holds staged row r; the two prefix sums
 // run over the lanes (no LDS, no barrier), every lane writes its own row's entries.
+// QUERY tiles (PCISPH with binned queries, k_pci_density_qtiled): `target_start` is then the prefix of the QUERY
+// histogram over the same grid cells -- the tile's targets are the query records of its 64 interior cells, its staged
+// rows the particles' as ever; target_start == cell_start is the particles' own build.
 __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
+                                                     const int* __restrict__ target_start,
                                                      const int* __restrict__ tiles, const int* __restrict__ n_tiles,
                                                      int* __restrict__ desc) {
   const int n = *n_tiles;
@@ -244,18 +248,19 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
   const int ry = lane % kTH, rz = lane / kTH;
   const bool row = lane < kTRows;
   const bool interior = row && ry >= 1 && ry <= kTB && rz >= 1 && rz <= kTB;
+  const bool queries = target_start != cell_start;
   // (two tiles per trip: the second one's loads travel under the first one's sums)
-  auto table = [&](int item, int tile, const TileSetupRegs& r) {
+  auto table = [&](int item, int tile, const TileSetupRegs& r, const TileSetupRegs& q) {
     TileMeta* out = reinterpret_cast<TileMeta*>(desc + (size_t)item * kMetaInts);
     const int len = r.s[kTH] - r.s[0];
     const int v = row ? len + kTPad : 0;
     const int inc = wave_inclusive_scan(v);  // LDS offsets: rows are kTPad apart
-    const int tv = interior ? r.s[kTB + 1] - r.s[1] : 0;
+    const int tv = interior ? q.s[kTB + 1] - q.s[1] : 0;
     const int tinc = wave_inclusive_scan(tv);  // targets: interior rows, interior cells
     int pv = 0;  // pair slots of the row's four interior cells
     if (interior) {
 #pragma unroll
-      for (int k = 1; k <= kTB; ++k) pv += (r.s[k + 1] - r.s[k] + 1) >> 1;
+      for (int k = 1; k <= kTB; ++k) pv += (q.s[k + 1] - q.s[k] + 1) >> 1;
     }
     const int pinc = wave_inclusive_scan(pv);
     if (row) {
@@ -270,14 +275,15 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
         const int ir = (rz - 1) * kTB + (ry - 1), t0 = tinc - tv;  // the row's first target
         out->tprefix[ir] = t0;
         out->pprefix[ir] = pinc - pv;
-        out->trow[ir] = make_int4(r.s[1] - t0, lds0 + (r.s[1] - r.s[0]) - t0,
-                                  (t0 + (r.s[2] - r.s[1])) | ((t0 + (r.s[3] - r.s[1])) << 16), t0 + (r.s[4] - r.s[1]));
+        out->trow[ir] = make_int4(q.s[1] - t0, lds0 + (r.s[1] - r.s[0]) - t0,
+                                  (t0 + (q.s[2] - q.s[1])) | ((t0 + (q.s[3] - q.s[1])) << 16), t0 + (q.s[4] - q.s[1]));
       }
       if (lane == kTRows - 1) {  // (the last interior row is lane 28: this lane's inclusive sums are the totals)
         out->row_lds[kTRows] = inc;
         // (a tile that overflows the LDS budget is never staged: its packed run bounds may be garbage.  Target
-        // indices fit 16 bits as long as the staged records do -- the targets are among them)
-        out->overflow = inc > kTCap ? 1 : 0;
+        // indices fit 16 bits as long as the staged records do -- the targets are among them; QUERY targets are not,
+        // and a tile with more of them than 16 bits count takes the global-memory sweep as well)
+        out->overflow = (inc > kTCap || tinc > 0xffff) ? 1 : 0;
         out->tprefix[kTB * kTB] = tinc;
         out->pprefix[kTB * kTB] = pinc;
         out->tile = tile;
@@ -294,8 +300,59 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
     TileSetupRegs r, r2;
     tile_setup_load(c, tg, tile, cell_start, r);
     if (two) tile_setup_load(c, tg, tile2, cell_start, r2);
-    table(item, tile, r);
-    if (two) table(item2, tile2, r2);
+    if (queries) {
+      TileSetupRegs q, q2;
+      tile_setup_load(c, tg, tile, target_start, q);
+      if (two) tile_setup_load(c, tg, tile2, target_start, q2);
+      table(item, tile, r, q);
+      if (two) table(item2, tile2, r2, q2);
+    } else {
+      table(item, tile, r, r);
+      if (two) table(item2, tile2, r2, r2);
+    }
+  }
+}
+
+// the tiles that hold at least one QUERY (PCISPH with binned queries): one list, in the boxed order of k_tile_list;
+// the list's length is cleared by k_pci_predict_bin at the head of the iteration
+__global__ __launch_bounds__(kBlock) void k_qtile_list(DevConsts c, TileGrid tg, const int* __restrict__ qstart,
+                                                       int* __restrict__ qtiles, int* __restrict__ n_qtiles,
+                                                       const DevStats* stats) {
+  if (stats->pci_done) return;
+  const int lt = blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
+  const int t = tile_of_list_thread(tg, lt);
+  int cnt = 0;
+  if (t >= 0) {
+    const int tx = t % tg.tnx, ty = (t / tg.tnx) % tg.tny, tz = t / (tg.tnx * tg.tny);
+    const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
+    const int xa = tx * kTB, xb = min(xa + kTB, nx);
+#pragma unroll
+    for (int dz = 0; dz < kTB; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < kTB; ++dy) {
+        const int z = tz * kTB + dz, y = ty * kTB + dy;
+        if (z < nz && y < ny) {
+          const int row = (z * ny + y) * nx;
+          cnt += qstart[row + xb] - qstart[row + xa];
+        }
+      }
+  }
+  __shared__ int wave_count[kBlock / kWave];
+  __shared__ int block_base;
+  const unsigned long long mine = __ballot(cnt > 0);
+  if (lane == 0) wave_count[wid] = __builtin_popcountll(mine);
+  sync_lds();
+  if (threadIdx.x == 0) {
+    int total = 0;
+    for (int w = 0; w < kBlock / kWave; ++w) total += wave_count[w];
+    block_base = total > 0 ? atomicAdd(n_qtiles, total) : 0;  // (one atomic per block: same-address atomics serialise)
+  }
+  sync_lds();
+  if (cnt > 0) {
+    int base = block_base;
+    for (int w = 0; w < wid; ++w) base += wave_count[w];
+    qtiles[base + __builtin_popcountll(mine & ((1ull << lane) - 1ull))] = t;
   }
 }
 
@@ -398,14 +455,14 @@ struct TileFeed {
   __device__ __forceinline__ TileFeed(const int* __restrict__ d, int n_tiles) : walk(n_tiles), desc_of(d) {
     int item;
     have_next = walk.next(item);
-    next = have_next ? desc_of[item] : 0;
+    next = have_next ? (desc_of ? desc_of[item] : item) : 0;  // (desc_of == nullptr: the list's own positions)
   }
   __device__ __forceinline__ bool pop(int& desc_index) {
     if (!have_next) return false;
     desc_index = next;
     int item;
     have_next = walk.next(item);
-    if (have_next) next = desc_of[item];
+    if (have_next) next = desc_of ? desc_of[item] : item;
     return true;
   }
 };
@@ -1949,7 +2006,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
                                                               const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                               const int* __restrict__ cell_start, Bnd bnd, CSoa3 p, Soa3 pp,
                                                               Soa3 pv, CSoa3 gterm, Soa3 frc, float* __restrict__ press,
-                                                              DevStats* stats) {
+                                                              unsigned int* __restrict__ drift, DevStats* stats) {
   if (stats->pci_done) return;
   // the LDS image is double-buffered exactly as in k_density_tiled: the next tile's loads are issued behind the
   // barrier that starts this tile's sweep, committed to the other image by every wave as soon as its own sweep is
@@ -1958,6 +2015,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
   __shared__ float4 Abuf[2][kTCap];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   unsigned int ebits = 0u;
+  unsigned int n_left = 0u, n_all = 0u;  // queries that have left their particle's tile / all (k_pci_predict_bin)
   auto load4 = [&](int g, float4* o) {
     o[0] = load4u(p.x + g);
     o[1] = load4u(p.y + g);
@@ -2014,6 +2072,8 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       const int ly = cell_coord(qy, c.gmin[1], c.inv_cell, c.dims[1]) - (ty * kTB - 1);
       const int lz = cell_coord(qz, c.gmin[2], c.inv_cell, c.dims[2]) - (tz * kTB - 1);
       const bool inside = lx >= 1 && lx <= kTB && ly >= 1 && ly <= kTB && lz >= 1 && lz <= kTB;
+      n_all += 1u;
+      n_left += inside ? 0u : 1u;
       float density;
       if (!ovf && inside) {
         const float rx = qx - ox, ry = qy - oy, rz = qz - oz;
@@ -2065,6 +2125,159 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
     }
   };
   TileFeed feed(desc_of, *n_tiles);
+  int di = 0;
+  bool have = feed.pop(di);
+  if (have) {
+    tile_meta_store(metas[0], tile_meta_request(desc, di));
+    bool have_next = feed.pop(di);
+    int table_word = have_next ? tile_meta_request(desc, di) : 0;
+    sync_lds();  // the first tile's table is visible
+    {
+      StageRegs<3> sr;
+      if (!metas[0].overflow) {
+        stage_issue<3>(metas[0], load4, sr);
+        commit(metas[0], sr, Abuf[0]);
+      }
+    }
+    if (have_next) tile_meta_store(metas[1], table_word);
+    int mc = 0, mn = 1, mnn = 2;  // tables of this tile, the next one, the one after
+    for (int cur = 0; have; cur ^= 1) {
+      sync_lds();  // image `cur` is complete, the next tile's table visible, image `cur ^ 1` and table `mnn` free
+      StageRegs<3> sr;
+      bool have_nn = false, stage_next = false;
+      table_word = 0;
+      if (have_next) {
+        stage_next = metas[mn].overflow == 0;
+        if (stage_next) stage_issue<3>(metas[mn], load4, sr);
+        have_nn = feed.pop(di);
+        if (have_nn) table_word = tile_meta_request(desc, di);
+      }
+      sweep(metas[mc], Abuf[cur]);
+      if (stage_next) commit(metas[mn], sr, Abuf[cur ^ 1]);
+      if (have_nn) tile_meta_store(metas[mnn], table_word);
+      have = have_next;
+      have_next = have_nn;
+      const int t = mc;
+      mc = mn;
+      mn = mnn;
+      mnn = t;
+    }
+  }
+  wave_atomic_max(&stats->pci_cur_err_bits, ebits);
+  pci_drift_add(drift, n_left, n_all);
+}
+
+// ---------------------------------------------------------------------------------
+// DensityF over BINNED queries, LDS-tiled (kernels_sph.hpp: k_pci_predict_bin has the why).  The tiles are those that
+// hold queries (k_qtile_list), a tile's table comes from k_tile_desc with the query prefix as its target table: targets
+// are the query records of the tile's 64 interior cells (predicted position + the particle's slot), candidates the
+// particles of the 6 x 6 x 6 cells around them, staged exactly as in k_pci_density_tiled, and the sweep is that
+// kernel's.  A query's cell comes from its place in the table -- the cell the sort put it in -- so a query that the
+// cell rule clamped into the grid's outermost cells (the predictor knows no walls: by step 1500 of the 4M scene four
+// out of five are below the floor) sweeps those cells' neighbourhood and finds nothing within h, as in the reference.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTBlock) void k_pci_density_qtiled(DevConsts c, TileGrid tg, const int* __restrict__ n_qtiles,
+                                                               const int* __restrict__ desc, const int* __restrict__ cell_start,
+                                                               CSoa3 p, const float4* __restrict__ qrec,
+                                                               float* __restrict__ press, DevStats* stats) {
+  if (stats->pci_done) return;
+  __shared__ TileMeta metas[3];
+  __shared__ float4 Abuf[2][kTCap];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  unsigned int ebits = 0u;
+  auto load4 = [&](int g, float4* o) {
+    o[0] = load4u(p.x + g);
+    o[1] = load4u(p.y + g);
+    o[2] = load4u(p.z + g);
+  };
+  auto load1 = [&](int g, float* o) {
+    o[0] = p.x[g];
+    o[1] = p.y[g];
+    o[2] = p.z[g];
+  };
+  auto commit = [&](const TileMeta& mt, const StageRegs<3>& sr, float4* img) {
+    const float ox = __int_as_float(mt.centre[0]), oy = __int_as_float(mt.centre[1]), oz = __int_as_float(mt.centre[2]);
+    stage_commit<3>(mt, sr, load1, [&](int slot, const float* o, bool real) {
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+      if (real) {
+        const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+        v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+      }
+      img[slot] = v;
+    });
+  };
+  auto sweep = [&](const TileMeta& m, const float4* __restrict__ A) {
+    const bool ovf = m.overflow != 0;
+    const float ox = __int_as_float(m.centre[0]), oy = __int_as_float(m.centre[1]), oz = __int_as_float(m.centre[2]);
+    const int ntarg = m.tprefix[kTB * kTB];
+    const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
+    for (int t = tperm; t < ntarg; t += kTBlock) {
+      float4 rec;
+      int lx = 1, qrow = 0;
+      if (!ovf) {
+        const TileTarget tt = tile_target(m, t);
+        rec = qrec[tt.g];
+        lx = tt.lx;
+        qrow = tt.srow;
+      } else {  // (no 16-bit cell boundaries to go by: the records of the tile's rows, one row after the other)
+        int ir = 0;
+        ir += (t >= m.tprefix[ir + 8]) ? 8 : 0;
+        ir += (t >= m.tprefix[ir + 4]) ? 4 : 0;
+        ir += (t >= m.tprefix[ir + 2]) ? 2 : 0;
+        ir += (t >= m.tprefix[ir + 1]) ? 1 : 0;
+        rec = qrec[m.trow[ir].x + t];
+      }
+      const float qx = rec.x, qy = rec.y, qz = rec.z;
+      const int g = __float_as_int(rec.w);
+      float density;
+      if (!ovf) {
+        const float rx = qx - ox, ry = qy - oy, rz = qz - oz;
+        const float two_hh = 2.0f * c.inv_hh;
+        const float sx = two_hh * rx, sy = two_hh * ry, sz = two_hh * rz;
+        const float a0 = 1.0f - c.inv_hh * __builtin_fmaf(rz, rz, __builtin_fmaf(ry, ry, rx * rx));
+        float acc = 0.f, acc1 = 0.f;
+        auto test4 = [&](int jj) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4 cnd = A[jj + u];
+            const float q = fma_clamp01(cnd.z, sz, __builtin_fmaf(cnd.y, sy, __builtin_fmaf(cnd.x, sx, cnd.w + a0)));
+            if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
+            else acc = __builtin_fmaf(q, q, acc);
+          }
+        };
+#pragma unroll 1
+        for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+          for (int dy = -1; dy <= 1; ++dy) {
+            int j, je;
+            tile_run(m, qrow + dz + dy, lx, j, je);
+            for (; j + 4 < je; j += 8) {
+              test4(j);
+              test4(j + 4);
+            }
+            if (j < je) test4(j);
+          }
+        }
+        density = __builtin_fmaf(acc + acc1, c.mass * c.A, c.W0);  // starts at W0, self included
+      } else {
+        density = c.W0;
+        for_each_grid_candidate(c, cell_start, qx, qy, qz, [&](int j) {
+          const float dx = qx - p.x[j], dy = qy - p.y[j], dz = qz - p.z[j];
+          const float r2 = dist2<true>(dx, dy, dz);
+          if (r2 < c.hh) {
+            const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+            density = __builtin_fmaf(c.mass * c.A, q * q, density);
+          }
+        });
+      }
+      const float density_error = density - c.ref_density;
+      const float abs_err = density_error * __builtin_amdgcn_rcpf(c.ref_density);
+      press[g] += density_error * c.delta;
+      const unsigned int eb = nonneg_bits(abs_err);
+      ebits = eb > ebits ? eb : ebits;
+    }
+  };
+  TileFeed feed(nullptr, *n_qtiles);
   int di = 0;
   bool have = feed.pop(di);
   if (have) {

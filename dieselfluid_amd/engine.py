@@ -295,6 +295,16 @@ class SPHEngine:
         """0 begin step, 1 iterate, 2 check, 3 end step (include/dslsph.h)"""
         self._ck(self._L.dsl_pcisph_phase(self._h, int(phase)))
 
+    def pcisph_set_binning(self, mode: int):
+        """-1 never, 0 automatic, 1 always: sort DensityF's query points into grid cells of their own (include/dslsph.h)"""
+        self._ck(self._L.dsl_pcisph_set_binning(self._h, int(mode)))
+
+    def pcisph_binning(self):
+        """(mode, active): active = the next correction iteration sorts its queries"""
+        m, a = C.c_int(0), C.c_int(0)
+        self._ck(self._L.dsl_pcisph_get_binning(self._h, C.byref(m), C.byref(a)))
+        return m.value, bool(a.value)
+
     def pcisph_error_word(self, dev_word: int, store: bool):
         self._ck(self._L.dsl_pcisph_error_word(self._h, C.c_void_p(dev_word), 1 if store else 0))
 

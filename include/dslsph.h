@@ -248,6 +248,16 @@ int dsl_pcisph_step(dsl_handle *h, int nsteps);
 enum { DSL_PCI_BEGIN_STEP = 0, DSL_PCI_ITERATE = 1, DSL_PCI_CHECK = 2, DSL_PCI_END_STEP = 3 };
 int dsl_pcisph_phase(dsl_handle *h, int phase);
 int dsl_pcisph_error_word(dsl_handle *h, uint32_t *dev_word, int store);
+/* DensityF's query points are the predictor's positions, and the reference never brings the predictor back to the
+ * particles (pcisph_darwin.go:28-41: `_pos`, `_vel` are seeded once, advanced in every correction iteration): within
+ * tens of steps they are cells, then whole tiles away from the particle they belong to.  The library then sorts the
+ * QUERIES into the particles' grid cells before every DensityF sweep (same candidates, same order, same arithmetic per
+ * query: DSL_MATH_EXACT results do not change by a bit).  mode 0 (default): switch when 1 % of the queries have left
+ * their particle's 4x4x4-cell tile -- looked at every 8 steps, the step's one host read-back, a one-way switch until the
+ * next dsl_pcisph_begin; 1: always; -1: never.  Environment DSL_PCI_BINNED presets the mode at dsl_create.
+ * dsl_pcisph_get_binning: the mode, and whether the next correction iteration sorts its queries (either may be NULL). */
+int dsl_pcisph_set_binning(dsl_handle *h, int mode);
+int dsl_pcisph_get_binning(dsl_handle *h, int *mode, int *active);
 
 int dsl_get_stats(dsl_handle *h, dsl_stats *out);
 int dsl_sync(dsl_handle *h); /* Queue.Finish() pcisph_gpu_darwin.go:261,271 */

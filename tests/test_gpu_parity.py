@@ -210,14 +210,17 @@ def test_wcsph_dambreak_10_steps(math_mode, tol_x):
     assert _agree(eng.download("densities"), ora.densities(), 10 * tol_x)
 
 
+@pytest.mark.parametrize("binning", [0, 1])
 @pytest.mark.parametrize("math_mode,tol", [(EXACT, 0), (FAST, 2e-4)])
-def test_pcisph_steps(math_mode, tol):
-    """PC: PciMethod.Run (pcisph_darwin.go:43-101), 2 steps with 5 and 4 max iterations."""
+def test_pcisph_steps(math_mode, tol, binning):
+    """PC: PciMethod.Run (pcisph_darwin.go:43-101), 2 steps with 5 and 4 max iterations.
+    binning = 1: DensityF's query points sorted into cells of their own (dsl_pcisph_set_binning), same bar."""
     p, pos, vel = _reference_system(12, math_mode, amp=0.1, vel_scale=0.05)
     for iters in (5, 4):
         p.pci_max_iters = iters
         p.delta = 1.0e-4
         eng = _engine(p)
+        eng.pcisph_set_binning(binning)
         eng.upload("positions", pos)
         eng.upload("velocities", vel)
         ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel)
@@ -235,8 +238,9 @@ def test_pcisph_steps(math_mode, tol):
         eng.close()
 
 
+@pytest.mark.parametrize("binning", [0, 1])
 @pytest.mark.parametrize("math_mode,tol", [(EXACT, 0), (FAST, 1e-4)])
-def test_pcisph_dambreak_scene(math_mode, tol):
+def test_pcisph_dambreak_scene(math_mode, tol, binning):
     """PCISPH on the dam-break block (h = 2dx, ~8 particles per cell): in FAST mode this is
     the LDS-tiled path (tiled viscosity sweep, cached gradient term, tiled DensityF), in
     EXACT mode the pass-by-pass kernels; both against the oracle's pcisph_darwin.go loop."""
@@ -248,12 +252,14 @@ def test_pcisph_dambreak_scene(math_mode, tol):
     vel = helpers.seeded_velocities(n3 ** 3, 0.2)
     frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (n3 ** 3, 1))
     eng = _engine(p)
+    eng.pcisph_set_binning(binning)
     eng.upload("positions", pos)
     eng.upload("velocities", vel)
     eng.upload("forces", frc)
     ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel, force=frc)
     ora.delta = p.delta
     eng.pcisph_begin(); ora.pcisph_begin()
+    assert eng.pcisph_binning() == (binning, bool(binning))
     for step in range(3):
         eng.pcisph_step(1); ora.pcisph_step(1)
         st = eng.stats()

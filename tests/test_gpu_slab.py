@@ -256,9 +256,13 @@ def _pci_single(n3, math_mode, extra, shuffle=False):
     return eng.download("positions")[inv], eng.download("velocities")[inv], st.pci_iters, st.pci_max_error
 
 
-@pytest.mark.parametrize("math_mode,world,n3,extra", [(0, 2, 16, False), (0, 3, 24, False), (0, 3, 24, True),
-                                                      (1, 2, 16, True), (1, 3, 24, True)])
-def test_pcisph_slabs_match_single_engine(tmp_path, math_mode, world, n3, extra):
+@pytest.mark.parametrize("math_mode,world,n3,extra,binned", [(0, 2, 16, False, 0), (0, 3, 24, False, 0), (0, 3, 24, True, 0),
+                                                             (1, 2, 16, True, 0), (1, 3, 24, True, 0),
+                                                             (0, 3, 24, True, 1), (1, 3, 24, True, 1)])
+def test_pcisph_slabs_match_single_engine(tmp_path, monkeypatch, math_mode, world, n3, extra, binned):
+    """binned = 1: every engine (the ranks' and the single one) sorts DensityF's query points into cells of their own
+    (DSL_PCI_BINNED=1: dsl_pcisph_set_binning) -- ghosts are no queries there either"""
+    monkeypatch.setenv("DSL_PCI_BINNED", str(binned))
     out = str(tmp_path / "slab_pci.npz")
     mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out), nprocs=world, join=True)
     z = np.load(out)
