@@ -48,6 +48,11 @@ def parse():
                     help="N=1 WCSPH only: after the timed region advance this many steps (the column collapses, the "
                          "lattice melts: ~10000 steps = 0.45 s of flow at n3=252) and time 20 more; reported as "
                          "developed_ms_per_step beside the headline.  0 = skip")
+    ap.add_argument("--drift-steps", type=int, default=400,
+                    help="N=1 --method pcisph only: after the timed region advance this many steps -- the reference never "
+                         "re-synchronises its predictor (pcisph_darwin.go:28-41), so DensityF's query points leave their "
+                         "particles and the library sorts them into cells of their own (dsl_pcisph_set_binning) -- and time "
+                         "20 more; reported under `drifted` beside the line.  0 = skip")
     ap.add_argument("--exact-steps", type=int, default=5,
                     help="N=1 WCSPH, --math fast only: also time this many steps of the SAME scene in DSL_MATH_EXACT (the "
                          "mode that is bit for bit the oracle's) on a second engine; reported under `exact`.  0 = skip")
@@ -193,14 +198,15 @@ def main():
         dt = float(t.item())
 
     eng = engines[0]
-    overflow = band_missed = 0
+    overflow = band_missed = query_escaped = 0
     if world > 1:
         # a band / capacity overflow or an outrun split margin would silently lose ghosts: make it visible
+        # (third word: a PCISPH query point has drifted out of its rank's ghost coverage -- include/dslsph.h)
         st4 = eng.slab_status()
-        ov = torch.tensor([st4[0], st4[1]], dtype=torch.int64,
+        ov = torch.tensor([st4[0], st4[1], int(eng.pcisph_query_escaped()) if args.method == "pcisph" else 0], dtype=torch.int64,
                           device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ov, op=dist.ReduceOp.MAX)
-        overflow, band_missed = int(ov[0].item()), int(ov[1].item())
+        overflow, band_missed, query_escaped = int(ov[0].item()), int(ov[1].item()), int(ov[2].item())
     def timing_of(k):  # N=1: the dominant kernels as timed inside the timed region
         return hot[k] if events_in_region and k in hot else eng.timing(k)
 
@@ -279,6 +285,27 @@ def main():
         developed = {"ms_per_step": round(td * 1e3, 4), "value": round(n_total / td / 1e6, 3), "kernels_ms": dk,
                      "after_steps": args.warmup + args.steps + timed_launch_steps + (args.developed_steps // chunk) * chunk,
                      "max_cell_count": sd.max_cell_count, "max_vel": sd.max_vel}
+    drifted = None
+    if world == 1 and args.method == "pcisph" and args.drift_steps > 0:
+        for e in engines:
+            e.timing_enable(False)
+        step(args.drift_steps)
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        step(20)
+        torch.cuda.synchronize()
+        td = (time.perf_counter() - td) / 20
+        eng.timing_reset()
+        eng.timing_enable(True)
+        step(5)
+        dk = {k: round(eng.timing(k)[0], 4) for k in ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous",
+                                                      "pci_predict", "pci_density", "update")}
+        eng.timing_enable(False)
+        drifted = {"ms_per_step": round(td * 1e3, 4), "value": round(n_total / td / 1e6, 3), "kernels_ms": dk,
+                   "after_steps": args.warmup + args.steps + timed_launch_steps + args.drift_steps,
+                   "queries_binned": bool(eng.pcisph_binning()[1]),
+                   "note": "pci_predict = predict + the queries' counting sort + query-tile tables, pci_density = the sweep; "
+                           "per correction iteration"}
     # HBM bytes per launch from the PMC counters cannot be sampled from inside this process;
     # they come from the committed rocprofv3 passes of this same command (profiles/traffic.json)
     # and are only quoted for the configuration they were measured on.
@@ -332,6 +359,7 @@ def main():
             "kernels_ms": kernels_ms,
             "slab_overflow": overflow,
             "slab_band_missed": band_missed,
+            "slab_pci_query_escaped": query_escaped,
             "slab_overlap": bool(world > 1 and drv.overlap),
             "kernel_events": ("density / force kernels in the timed region, the others in a "
                               f"{timed_launch_steps}-step segment after it") if events_in_region else
@@ -339,6 +367,7 @@ def main():
             "max_vel": st.max_vel,
             "max_cell_count": st.max_cell_count,
             "developed": developed,
+            "drifted": drifted,
             "exact": exact,
             "n_live_rank0": n_live,
             "slab_driver": (("native (dsl_slab_wcsph_step: RCCL inside libdslsph.so)" if backend == "nccl" else

@@ -569,8 +569,16 @@ func (e *Engine) PCISPHSetBinning(mode int) error {
 // PCISPHBinning: the mode, and whether the next correction iteration will sort its queries.
 func (e *Engine) PCISPHBinning() (mode int, active bool, err error) {
 	var m, a C.int
-	err = e.ck(C.dsl_pcisph_get_binning(e.h, &m, &a))
+	err = e.ck(C.dsl_pcisph_get_binning(e.h, &m, &a, nil))
 	return int(m), a != 0, err
+}
+
+// PCISPHQueryEscaped (slab mode, blocking): a query point of an owned particle has drifted more than h beyond a slab
+// plane, out of what the 2h ghost band covers.
+func (e *Engine) PCISPHQueryEscaped() (bool, error) {
+	var x C.int
+	err := e.ck(C.dsl_pcisph_get_binning(e.h, nil, nil, &x))
+	return x != 0, err
 }
 
 // NewCommAll: one process, several devices (ncclCommInitAll); NewEngines wraps it together with the handles.

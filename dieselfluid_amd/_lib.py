@@ -115,7 +115,7 @@ EXPORTS = {
     "dsl_pcisph_phase": (C.c_int, [_vp, C.c_int]),
     "dsl_pcisph_error_word": (C.c_int, [_vp, _vp, C.c_int]),
     "dsl_pcisph_set_binning": (C.c_int, [_vp, C.c_int]),
-    "dsl_pcisph_get_binning": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dsl_pcisph_get_binning": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dsl_slab_split": (C.c_int, [_vp, C.c_float, C.c_float]),
     "dsl_slab_pack": (C.c_int, [_vp, C.c_float, C.c_float, _vp, _vp, C.c_int, C.c_int]),
     "dsl_slab_pack_band": (C.c_int, [_vp, C.c_float, _vp, _vp, C.c_int, C.c_int, _vp]),

@@ -78,7 +78,7 @@ struct dsl_handle {
   float* gterm[3] = {};  // PCISPH: cached pressure-gradient force term
   // PCISPH with the DensityF query points in bins of their own (kernels_sph.hpp: k_pci_predict_bin): the histogram over
   // the particles' grid cells, its prefix, the scan's tile sums, one record per query, and the 512 drift counters the
-  // un-binned kernels keep.  pci_bin_mode: 0 = the library switches when 1 % of the predicted positions have left their
+  // un-binned kernels keep.  pci_bin_mode: 0 = the library switches when 0.2 % of the predicted positions have left their
   // particle's tile (looked at every kPciDriftPeriod steps; a one-way latch until the next dsl_pcisph_begin), 1 = always,
   // -1 = never (dsl_pcisph_set_binning; DSL_PCI_BINNED presets it)
   int pci_bin_mode = 0;
@@ -89,6 +89,9 @@ struct dsl_handle {
   int *qtiles = nullptr, *n_qtiles = nullptr, *qtile_desc = nullptr;  // FAST: the tiles that hold queries and their tables
   float4* qrec = nullptr;
   unsigned int* pci_drift = nullptr;
+  unsigned int* pci_drift_host = nullptr;  // pinned: the snapshot of the counters the next look reads
+  hipEvent_t ev_drift = nullptr;
+  bool drift_pending = false;
   float* xsph[3] = {};   // build-defined XSPH correction of the current step (PCISPH path)
   unsigned int* nmask = nullptr;  // FAST: per-particle in-range masks from the density sweep (kMaskWords x cap)
   bool masks_valid = false;
@@ -768,6 +771,8 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->n_qtiles);
   (void)hipFree(h->qtile_desc);
   (void)hipFree(h->pci_drift);
+  if (h->pci_drift_host) (void)hipHostFree(h->pci_drift_host);
+  if (h->ev_drift) (void)hipEventDestroy(h->ev_drift);
   (void)hipFree(h->scan_status);
   (void)hipFree(h->scan_ticket);
   (void)hipFree(h->stage);
@@ -809,6 +814,8 @@ int alloc_pci(dsl_handle* h) {
         if (int rc = dev_alloc(h, &h->pci[w][k], (size_t)h->cap)) return rc;
   if (!h->pci_drift)
     if (int rc = dev_alloc(h, &h->pci_drift, (size_t)512)) return rc;
+  if (!h->pci_drift_host) HIP_TRY(h, hipHostMalloc((void**)&h->pci_drift_host, 512 * sizeof(unsigned int), hipHostMallocDefault));
+  if (!h->ev_drift) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_drift, hipEventDisableTiming));
   return DSL_OK;
 }
 
@@ -1525,28 +1532,43 @@ int dsl_pcisph_begin(dsl_handle* h) {
   if (h->pci_steps != 0) HIP_TRY(h, hipMemsetAsync(h->pci_drift, 0, 512 * sizeof(unsigned int), h->stream));
   h->pci_steps = 0;
   h->pci_binned = false;
+  h->drift_pending = false;
+  HIP_TRY(h, hipMemsetAsync(&h->dstats->pci_escaped, 0, sizeof(int), h->stream));
   return DSL_OK;
 }
 
 namespace {
-constexpr int kPciDriftPeriod = 8;         // steps between two looks at the drift counters
-constexpr double kPciDriftFraction = 0.01;  // of the predicted positions outside their particle's tile: bin the queries
+// Measured on the 4M scene (tools/pci_switch_point.py, profiles/r03_pci_switch_point.jsonl): one correction iteration
+// of the un-binned form costs 0.24 ms while every query sits in its particle's tile, 0.35 with 0.2 % of them outside
+// (a wave with one such lane sweeps global memory for it), 0.83 with 1.9 %; the binned form 0.37 .. 0.48 whatever the
+// drift.  Hence the low threshold and the short period.
+constexpr int kPciDriftPeriod = 4;           // steps between two looks at the drift counters
+constexpr double kPciDriftFraction = 0.002;  // of the predicted positions outside their particle's tile: bin the queries
 
-// Every kPciDriftPeriod steps: how many DensityF query points have left their particle's tile since the last look
-// (counted by the un-binned kernels).  The one host read-back of the PCISPH step -- 2 KB, at a step boundary that is
-// a function of the step count alone, so a run's arithmetic does not depend on how its steps were grouped into calls.
+// Every kPciDriftPeriod steps: how many DensityF query points have left their particle's tile (counted by the un-binned
+// kernels)?  No stall: the counters are copied to pinned memory asynchronously and cleared, and it is the NEXT look, a
+// period of queued steps later, that reads the copy (waiting for its event only throttles a host that has run more than
+// a period ahead of the device).  Both happen at step counts fixed in advance, so a run's arithmetic does not depend on
+// how its steps were grouped into calls or on timing.
 int pci_drift_check(dsl_handle* h) {
   if (h->pci_bin_mode != 0 || h->pci_binned || h->lsh || h->pci_steps == 0 || h->pci_steps % kPciDriftPeriod != 0) return DSL_OK;
-  unsigned int cnt[512];
-  HIP_TRY(h, hipMemcpyAsync(cnt, h->pci_drift, sizeof(cnt), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  unsigned long long left = 0, all = 0;
-  for (int k = 0; k < 256; ++k) {
-    left += cnt[k];
-    all += cnt[256 + k];
+  if (h->drift_pending) {
+    HIP_TRY(h, hipEventSynchronize(h->ev_drift));
+    h->drift_pending = false;
+    unsigned long long left = 0, all = 0;
+    for (int k = 0; k < 256; ++k) {
+      left += h->pci_drift_host[k];
+      all += h->pci_drift_host[256 + k];
+    }
+    if (all != 0 && (double)left > kPciDriftFraction * (double)all) {
+      h->pci_binned = true;
+      return DSL_OK;
+    }
   }
-  if (all != 0 && (double)left > kPciDriftFraction * (double)all) h->pci_binned = true;
-  else HIP_TRY(h, hipMemsetAsync(h->pci_drift, 0, sizeof(cnt), h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->pci_drift_host, h->pci_drift, 512 * sizeof(unsigned int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipEventRecord(h->ev_drift, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->pci_drift, 0, 512 * sizeof(unsigned int), h->stream));
+  h->drift_pending = true;
   return DSL_OK;
 }
 
@@ -1613,11 +1635,11 @@ int pci_iterate(dsl_handle* h) {
     int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
       if (tiled)
         hipLaunchKernelGGL((k_pci_predict_bin<false, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
-                           h->qcount, h->rank, h->n_qtiles, h->pci_drift, h->dcounter + 4, h->press, h->dstats);
+                           h->qcount, h->rank, h->n_qtiles, nullptr, h->dcounter + 4, h->press, h->dstats);
       else
         by_math(h, [&](auto fast) {
           hipLaunchKernelGGL((k_pci_predict_bin<true, false, decltype(fast)::value>), g, b, 0, h->stream, c, bnd_of(h), p, pp,
-                             pvv, cG, F, h->qcount, h->rank, nullptr, h->pci_drift, h->dcounter + 4, h->press, h->dstats);
+                             pvv, cG, F, h->qcount, h->rank, nullptr, nullptr, h->dcounter + 4, h->press, h->dstats);
         });
       hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, nullptr, nullptr);
       hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, h->qstart, nullptr);
@@ -1729,10 +1751,16 @@ int dsl_pcisph_set_binning(dsl_handle* h, int mode) {
   return DSL_OK;
 }
 
-int dsl_pcisph_get_binning(dsl_handle* h, int* mode, int* active) {
+int dsl_pcisph_get_binning(dsl_handle* h, int* mode, int* active, int* escaped) {
   CHECK_HANDLE(h);
   if (mode) *mode = h->pci_bin_mode;
   if (active) *active = (!h->lsh && (h->pci_bin_mode > 0 || (h->pci_bin_mode == 0 && h->pci_binned))) ? 1 : 0;
+  if (escaped) {  // (the one blocking part: the flag lives on the device)
+    int e = 0;
+    HIP_TRY(h, hipMemcpyAsync(&e, &h->dstats->pci_escaped, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *escaped = e ? 1 : 0;
+  }
   return DSL_OK;
 }
 

@@ -529,7 +529,7 @@ __device__ __forceinline__ bool pci_left_tile(const DevConsts& c, float x, float
 __device__ __forceinline__ void pci_drift_add(unsigned int* __restrict__ drift, unsigned int n_out, unsigned int n_all);
 // (`drift`: how many predicted positions have left their particle's tile, see k_pci_predict_bin; nullptr in LSH mode)
 __global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, Bnd bnd, CSoa3 p, CSoa3 f, Soa3 pp, Soa3 pv,
-                                                        unsigned int* __restrict__ drift, const DevStats* stats) {
+                                                        unsigned int* __restrict__ drift, DevStats* stats) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   bool mine = false, left = false;
@@ -547,6 +547,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict(DevConsts c, Bnd bnd, CS
     pv.z[i] = tvz;
     mine = true;
     if (drift != nullptr) left = pci_left_tile(c, p.x[i], p.y[i], p.z[i], qx, qy, qz);
+    if (c.slab_axis >= 0 && slab_owned(c, p.x[i], p.y[i], p.z[i]) && pci_query_escaped(c, qx, qy, qz)) stats->pci_escaped = 1;
   }
   if (drift != nullptr) pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
 }
@@ -648,7 +649,8 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
   int cell = -1;
   bool left = false, mine = false;
   unsigned int err_bits = 0u;
-  if (i < live_n(c) && !bnd.is(i) && (GHOSTS || slab_owned(c, p.x[i], p.y[i], p.z[i]))) {
+  // (the particle's own position is only read where something asks for it: slab ownership, the drift statistic)
+  if (i < live_n(c) && !bnd.is(i) && (GHOSTS || c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i]))) {
     const float fx = frc.x[i], fy = frc.y[i], fz = frc.z[i];
     const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
     const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
@@ -667,7 +669,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
       frc.z[i] = fz + gterm.z[i];
     }
     mine = true;
-    left = pci_left_tile(c, p.x[i], p.y[i], p.z[i], qx, qy, qz);
+    if (drift != nullptr) left = pci_left_tile(c, p.x[i], p.y[i], p.z[i], qx, qy, qz);
+    if (c.slab_axis >= 0 && (!GHOSTS || slab_owned(c, p.x[i], p.y[i], p.z[i])) && pci_query_escaped(c, qx, qy, qz))
+      stats->pci_escaped = 1;
     bool far = false;
     if (all_inside) {
 #pragma unroll
@@ -680,11 +684,16 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
       const float density_error = c.W0 - c.ref_density;
       const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
       press[i] += density_error * c.delta;
-      if (!GHOSTS || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
+      if (!GHOSTS || c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
     } else {
       cell = cell_of(c, qx, qy, qz);
     }
   }
+  // Equal-cell runs of consecutive lanes share one atomic (early on the queries of a cell's particles are still
+  // together).  Later they are not: 64 consecutive particles' queries sit in 62 different cells by step 400 of the 4M
+  // scene (tools/pci_query_spread.py) -- the drift is noisy, not a smooth displacement -- and grouping equal cells across
+  // the whole wave (tried) then finds nothing to group.  Those ~4M device-scope atomics with a return value on random
+  // words of a 16 MB histogram are ~120 us of this kernel, about what that many random 64-byte accesses cost.
   const int prev = __shfl_up(cell, 1, kWave);
   const bool head = (lane == 0) || (cell != prev);
   const unsigned long long heads = __ballot(head);
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
   if (lane == head_lane && cell >= 0) base = atomicAdd(&qcount[cell], next - head_lane);
   base = __shfl(base, head_lane, kWave);
   if (i < live_n(c)) qrank[i] = cell >= 0 ? base + (lane - head_lane) : -1;
-  pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
+  if (drift != nullptr) pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
   wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
 }
 
@@ -746,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_density_binned(DevConsts c, Neig
     const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
     const float dp = density_error * c.delta;
     press[i] += dp;
-    if (slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
+    if (c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
   }
   wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
 }

@@ -2074,6 +2074,7 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_tiled(DevConsts c, Tile
       const bool inside = lx >= 1 && lx <= kTB && ly >= 1 && ly <= kTB && lz >= 1 && lz <= kTB;
       n_all += 1u;
       n_left += inside ? 0u : 1u;
+      if (pci_query_escaped(c, qx, qy, qz)) stats->pci_escaped = 1;
       float density;
       if (!ovf && inside) {
         const float rx = qx - ox, ry = qy - oy, rz = qz - oz;

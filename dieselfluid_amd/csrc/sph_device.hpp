@@ -85,6 +85,10 @@ struct DevStats {
   int max_cell_count;
   int band_missed;  // split slab step: an interior particle moved further than the split margin
   int scan_stuck;   // k_scan_onepass gave up waiting for a predecessor tile (never in a healthy run): the build is void
+  // slab mode, PCISPH: a DensityF query point (the predictor's position, which the reference never re-synchronises)
+  // lies more than h beyond a slab plane, i.e. outside what the 2h ghost band covers: its sum is missing neighbours
+  // that live on another rank, and the run no longer equals the single-domain run (dsl_slab_status[1], bit 1)
+  int pci_escaped;
 };
 
 // ---------------------------------------------------------------------------------
@@ -225,6 +229,13 @@ __device__ __forceinline__ bool slab_owned(const DevConsts& c, float x, float y,
   if (c.slab_axis < 0) return true;
   const float p = c.slab_axis == 0 ? x : (c.slab_axis == 1 ? y : z);
   return p >= c.slab_lo && p < c.slab_hi;  // false for NaN
+}
+
+// slab mode: has a PCISPH query point left the region this rank's particles + 2h ghost band cover (see DevStats)?
+__device__ __forceinline__ bool pci_query_escaped(const DevConsts& c, float qx, float qy, float qz) {
+  if (c.slab_axis < 0) return false;
+  const float q = c.slab_axis == 0 ? qx : (c.slab_axis == 1 ? qy : qz);
+  return q < c.slab_lo - c.h || q >= c.slab_hi + c.h;
 }
 
 // Split slab step: the force pass first integrates the particles of the BAND cell layers --

@@ -302,8 +302,14 @@ class SPHEngine:
     def pcisph_binning(self):
         """(mode, active): active = the next correction iteration sorts its queries"""
         m, a = C.c_int(0), C.c_int(0)
-        self._ck(self._L.dsl_pcisph_get_binning(self._h, C.byref(m), C.byref(a)))
+        self._ck(self._L.dsl_pcisph_get_binning(self._h, C.byref(m), C.byref(a), None))
         return m.value, bool(a.value)
+
+    def pcisph_query_escaped(self) -> bool:
+        """slab mode: has a DensityF query point left what the ghost band covers (include/dslsph.h)?  Blocking."""
+        e = C.c_int(0)
+        self._ck(self._L.dsl_pcisph_get_binning(self._h, None, None, C.byref(e)))
+        return bool(e.value)
 
     def pcisph_error_word(self, dev_word: int, store: bool):
         self._ck(self._L.dsl_pcisph_error_word(self._h, C.c_void_p(dev_word), 1 if store else 0))

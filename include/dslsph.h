@@ -252,12 +252,17 @@ int dsl_pcisph_error_word(dsl_handle *h, uint32_t *dev_word, int store);
  * particles (pcisph_darwin.go:28-41: `_pos`, `_vel` are seeded once, advanced in every correction iteration): within
  * tens of steps they are cells, then whole tiles away from the particle they belong to.  The library then sorts the
  * QUERIES into the particles' grid cells before every DensityF sweep (same candidates, same order, same arithmetic per
- * query: DSL_MATH_EXACT results do not change by a bit).  mode 0 (default): switch when 1 % of the queries have left
- * their particle's 4x4x4-cell tile -- looked at every 8 steps, the step's one host read-back, a one-way switch until the
- * next dsl_pcisph_begin; 1: always; -1: never.  Environment DSL_PCI_BINNED presets the mode at dsl_create.
- * dsl_pcisph_get_binning: the mode, and whether the next correction iteration sorts its queries (either may be NULL). */
+ * query: DSL_MATH_EXACT results do not change by a bit).  mode 0 (default): switch when 0.2 % of the queries have left
+ * their particle's 4x4x4-cell tile -- looked at every 4 steps through an asynchronous copy of the device's
+ * counters that the next look reads (no stall; the decision trails the drift by 4 to 8 steps), a one-way switch until
+ * the next dsl_pcisph_begin; 1: always; -1: never.  Environment DSL_PCI_BINNED presets the mode at dsl_create.
+ * dsl_pcisph_get_binning: the mode; whether the next correction iteration sorts its queries; and, slab mode (blocking
+ * if asked for), whether a query point of an owned particle has drifted more than h beyond a slab plane since
+ * dsl_pcisph_begin, i.e. out of what the 2h ghost band covers: from then on this rank's predicted densities -- the
+ * pressure accumulator and the iteration's convergence error, nothing else reads them (pcisph_darwin.go:76-98) -- miss
+ * neighbours that live on another rank.  Any of the three pointers may be NULL. */
 int dsl_pcisph_set_binning(dsl_handle *h, int mode);
-int dsl_pcisph_get_binning(dsl_handle *h, int *mode, int *active);
+int dsl_pcisph_get_binning(dsl_handle *h, int *mode, int *active, int *escaped);
 
 int dsl_get_stats(dsl_handle *h, dsl_stats *out);
 int dsl_sync(dsl_handle *h); /* Queue.Finish() pcisph_gpu_darwin.go:261,271 */

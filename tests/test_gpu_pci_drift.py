@@ -1,10 +1,10 @@
 """PCISPH over more than a handful of steps.  The reference seeds its predictor state once (pcisph_darwin.go:28-41) and
 advances it in every correction iteration (:57-73) without ever copying the particles back into it, so the points
 DensityF is evaluated at (sph_field.go:137-152) drift away from the particles they belong to -- cells, then tiles, then
-the whole box.  The library follows them: once 1 % have left their particle's tile it sorts the QUERY points into grid
+the whole box.  The library follows them: once 0.2 % have left their particle's tile it sorts the QUERY points into grid
 cells of their own before every DensityF sweep (kernels_sph.hpp: k_pci_predict_bin ... k_pci_density_binned).  Nothing a
 host can observe may change with that switch in DSL_MATH_EXACT, and in DSL_MATH_FAST a run must not depend on how its
-steps were grouped into calls (the switch is looked at every 8 steps, a function of the step count alone)."""
+steps were grouped into calls (the switch is looked at every 4 steps, a function of the step count alone)."""
 import numpy as np
 import pytest
 
@@ -48,8 +48,8 @@ def test_exact_run_through_the_switch_is_the_oracles_bit_for_bit():
     eng.pcisph_begin(); ora.pcisph_begin()
     assert eng.pcisph_binning() == (0, False)
     seen = []
-    for chunk in range(5):
-        eng.pcisph_step(8); ora.pcisph_step(8)
+    for chunk in range(10):
+        eng.pcisph_step(4); ora.pcisph_step(4)
         st = eng.stats()
         seen.append(eng.pcisph_binning()[1])
         assert st.pci_iters == ora.pci_iters
@@ -58,7 +58,7 @@ def test_exact_run_through_the_switch_is_the_oracles_bit_for_bit():
                            ("pci_positions", ora.pci_positions()), ("pci_velocities", ora.pci_velocities())):
             assert np.array_equal(eng.download(name).view(np.uint32), want.view(np.uint32)), (name, chunk)
     frac = _tile_leavers(p, eng.download("positions"), eng.download("pci_positions"))
-    print(f"binning active after each 8 steps: {seen}; {frac:.3f} of the predicted positions are in another tile")
+    print(f"binning active after each 4 steps: {seen}; {frac:.3f} of the predicted positions are in another tile")
     assert frac > 0.05 and seen[-1] and not seen[0]
     eng.close()
 
@@ -66,7 +66,7 @@ def test_exact_run_through_the_switch_is_the_oracles_bit_for_bit():
 @pytest.mark.parametrize("mode", [0, 1, -1])
 def test_fast_run_does_not_depend_on_call_grouping(mode):
     """40 FAST steps as 40 calls of one step, 5 calls of 8 and the phase-by-phase form: the same bits, whatever the
-    binning mode (0 = the library decides, at steps 8, 16, 24 and 32)."""
+    binning mode (0 = the library decides, every 4 steps)."""
     from dieselfluid_amd import SPHEngine
     p, pos = _scene(16, FAST)
     res = []
@@ -95,7 +95,7 @@ def test_fast_run_does_not_depend_on_call_grouping(mode):
         for a, b in zip(res[0][:4], r[:4]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         assert r[4] == res[0][4]
-    assert res[0][4] == (mode >= 0)  # by step 32 more than 1 % of the queries have left their tile
+    assert res[0][4] == (mode >= 0)  # by step 36 more than 0.2 % of the queries have left their tile
 
 
 def test_binned_density_matches_a_float64_brute_force_after_the_drift():

@@ -205,7 +205,7 @@ def _pci_params(p, extra):
         p.st_kappa = 25.0 * p.h * p.h
 
 
-def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False):
+def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False, steps=None):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -218,12 +218,13 @@ def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False):
                               params_hook=lambda p: _pci_params(p, extra),
                               vel_fn=lambda ids, pos: 0.5 * _vel_fn(ids, pos, axis=2))
     assert drv.engine.eng.slab_record_floats() == 13
-    drv.pcisph_step(STEPS)
+    drv.pcisph_step(STEPS if steps is None else steps)
     res = drv.gather_state(n3 ** 3)
     st = drv.engine.status()
     stats = drv.engine_core.stats()
     info = [None] * world if rank == 0 else None
-    dist.gather_object((drv.engine_core.n_owned(), st[0], stats.pci_iters, stats.pci_max_error), info, dst=0)
+    dist.gather_object((drv.engine_core.n_owned(), st[0], stats.pci_iters, stats.pci_max_error,
+                        int(drv.engine_core.pcisph_query_escaped())), info, dst=0)
     calls = [None] * world if rank == 0 else None
     dist.gather_object(list(drv.engine_core._comm.calls) if native else [], calls, dst=0)
     if rank == 0:
@@ -289,6 +290,21 @@ def test_pcisph_slabs_match_single_engine(tmp_path, monkeypatch, math_mode, worl
     print(f"pcisph slab-vs-single x {ex:.2e} (tol {tol_x:.2e})  v {ev:.2e} (tol {tol_v:.2e})  iters {iters} err {err:.3e}")
     assert ex < tol_x
     assert ev < tol_v
+
+
+def test_pcisph_slabs_report_queries_that_left_the_ghost_coverage(tmp_path):
+    """The reference never re-synchronises its predictor, so DensityF's query points drift away from their particles; a
+    slab's ghosts cover 2h beyond its planes, i.e. queries up to h beyond them.  A run stays the single-domain run only
+    until the first query is further out -- the library says when (dsl_pcisph_get_binning's third word), here within 40
+    steps of a 24^3 block on three ranks (slabs 4h thick), and not in the first."""
+    out = str(tmp_path / "slab_pci_escape.npz")
+    flags = []
+    for steps in (1, 40):
+        mp.spawn(_pci_worker, args=(3, _free_port(), 1, 24, False, out, False, steps), nprocs=3, join=True)
+        info = np.load(out)["info"]
+        assert np.all(info[:, 1] == 0)
+        flags.append(int(info[:, 4].max()))
+    assert flags == [0, 1]
 
 
 def _load_calls(out):
