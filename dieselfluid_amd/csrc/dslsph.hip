@@ -83,6 +83,7 @@ struct dsl_handle {
   // -1 = never (dsl_pcisph_set_binning; DSL_PCI_BINNED presets it)
   int pci_bin_mode = 0;
   bool pci_binned = false;
+  bool pci_qpair = true;   // ... two queries per lane (DSL_PCI_QPAIR=0: one)
   bool pci_qtiled = true;  // FAST: sweep the binned queries tile by tile out of LDS (DSL_PCI_QTILED=0: the global-memory sweep)
   int64_t pci_steps = 0;  // completed steps since dsl_pcisph_begin
   int *qcount = nullptr, *qstart = nullptr, *qsums = nullptr;
@@ -973,6 +974,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   if (const char* e = std::getenv("DSL_SCAN_ONEPASS")) h->scan_onepass = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_DENSITY_PAIR")) h->density_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_QTILED")) h->pci_qtiled = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DSL_PCI_QPAIR")) h->pci_qpair = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_BINNED")) {  // -1 never, 0 automatic, 1 always (dsl_pcisph_set_binning)
     const int m = std::atoi(e);
     h->pci_bin_mode = m < 0 ? -1 : (m > 0 ? 1 : 0);
@@ -1654,8 +1656,12 @@ int pci_iterate(dsl_handle* h) {
     if (rc) return rc;
     rc = timed(h, DSL_K_PCI_DENSITY, [&] {
       if (tiled && h->pci_qtiled) {
-        hipLaunchKernelGGL(k_pci_density_qtiled, dim3(persistent_grid(h, 2)), dim3(kTBlock), 0, h->stream, c, h->tg,
-                           h->n_qtiles, h->qtile_desc, h->cell_start, p, h->qrec, h->press, h->dstats);
+        if (h->pci_qpair)  // two queries of one cell per lane (256-thread workgroups, four per CU)
+          hipLaunchKernelGGL(k_pci_density_qpair, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
+                             h->n_qtiles, h->qtile_desc, h->cell_start, p, h->qrec, h->press, h->dstats);
+        else
+          hipLaunchKernelGGL(k_pci_density_qtiled, dim3(persistent_grid(h, 2)), dim3(kTBlock), 0, h->stream, c, h->tg,
+                             h->n_qtiles, h->qtile_desc, h->cell_start, p, h->qrec, h->press, h->dstats);
         return;
       }
       by_math(h, [&](auto fast) {

@@ -2320,4 +2320,170 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_qtiled(DevConsts c, Til
   wave_atomic_max(&stats->pci_cur_err_bits, ebits);
 }
 
+// The same sweep with TWO queries of one cell per lane (k_density_pair's scheme: every staged record read once and
+// tested twice, every run set up once for two; 256-thread workgroups, four per CU, single-buffered).  Binned queries are
+// what makes this possible for DensityF: the un-binned kernel's targets are the particles of a cell, whose query points
+// the reference never brings back to that cell.  A slot is two queries of one cell or a cell's odd one out
+// (TileMeta::pprefix, here over the QUERY counts); short last passes are shared out among 2 .. 16 lanes per slot.
+__global__ __launch_bounds__(kPBlock, 4) void k_pci_density_qpair(DevConsts c, TileGrid tg, const int* __restrict__ n_qtiles,
+                                                                 const int* __restrict__ desc, const int* __restrict__ cell_start,
+                                                                 CSoa3 p, const float4* __restrict__ qrec,
+                                                                 float* __restrict__ press, DevStats* stats) {
+  if (stats->pci_done) return;
+  __shared__ TileMeta metas[2];
+  __shared__ float4 A[kTCap];
+  const int tid = threadIdx.x;
+  unsigned int ebits = 0u;
+  auto load4 = [&](int g, float4* o) {
+    o[0] = load4u(p.x + g);
+    o[1] = load4u(p.y + g);
+    o[2] = load4u(p.z + g);
+  };
+  auto load1 = [&](int g, float* o) {
+    o[0] = p.x[g];
+    o[1] = p.y[g];
+    o[2] = p.z[g];
+  };
+  auto meta_request = [&](int desc_index, int (&w)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * kPBlock;
+      w[k] = i < kMetaInts ? desc[(size_t)desc_index * kMetaInts + i] : 0;
+    }
+  };
+  auto meta_store = [&](TileMeta& m, const int (&w)[2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * kPBlock;
+      if (i < kMetaInts) reinterpret_cast<int*>(&m)[i] = w[k];
+    }
+  };
+  auto finish = [&](int g, float density) {  // pressure accumulate + the iteration's error (pcisph_darwin.go:76-92)
+    const float density_error = density - c.ref_density;
+    const float abs_err = density_error * __builtin_amdgcn_rcpf(c.ref_density);
+    press[g] += density_error * c.delta;
+    const unsigned int eb = nonneg_bits(abs_err);
+    ebits = eb > ebits ? eb : ebits;
+  };
+  TileFeed feed(nullptr, *n_qtiles);
+  int di = 0;
+  bool have = feed.pop(di);
+  if (have) {
+    int w[2];
+    meta_request(di, w);
+    meta_store(metas[0], w);
+  }
+  for (int cur = 0; have; cur ^= 1) {
+    TileMeta& m = metas[cur];
+    sync_lds();  // the previous tile's sweep is over: its LDS records are free, this tile's table is visible
+    have = feed.pop(di);
+    int tw[2] = {0, 0};
+    if (have) meta_request(di, tw);
+    const bool ovf = m.overflow != 0;
+    const float ox = __int_as_float(m.centre[0]), oy = __int_as_float(m.centre[1]), oz = __int_as_float(m.centre[2]);
+    if (!ovf) {
+      auto store = [&](int slot, const float* o, bool real) {
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, -1.0e30f);  // pad: q = clamp(-1e30 + ...) = 0
+        if (real) {
+          const float x = o[0] - ox, y = o[1] - oy, z = o[2] - oz;
+          v = make_float4(x, y, z, -c.inv_hh * __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+        }
+        A[slot] = v;
+      };
+      StageRegs<3> sr0, sr1;
+      stage_issue<3>(m, load4, sr0, tid);
+      stage_issue<3>(m, load4, sr1, tid + kPBlock);
+      stage_commit<3>(m, sr0, load1, store, tid);
+      stage_commit<3>(m, sr1, load1, store, tid + kPBlock);
+    }
+    if (have) meta_store(metas[cur ^ 1], tw);
+    sync_lds();
+    if (ovf) {
+      // (more candidates than the LDS image holds, or more queries than 16 bits count: one query per lane, global memory)
+      const int ntarg = m.tprefix[kTB * kTB];
+      for (int t = tid; t < ntarg; t += kPBlock) {
+        int ir = 0;
+        ir += (t >= m.tprefix[ir + 8]) ? 8 : 0;
+        ir += (t >= m.tprefix[ir + 4]) ? 4 : 0;
+        ir += (t >= m.tprefix[ir + 2]) ? 2 : 0;
+        ir += (t >= m.tprefix[ir + 1]) ? 1 : 0;
+        const float4 rec = qrec[m.trow[ir].x + t];
+        float density = c.W0;
+        for_each_grid_candidate(c, cell_start, rec.x, rec.y, rec.z, [&](int j) {
+          const float dx = rec.x - p.x[j], dy = rec.y - p.y[j], dz = rec.z - p.z[j];
+          const float r2 = dist2<true>(dx, dy, dz);
+          if (r2 < c.hh) {
+            const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+            density = __builtin_fmaf(c.mass * c.A, q * q, density);
+          }
+        });
+        finish(__float_as_int(rec.w), density);
+      }
+      continue;
+    }
+    const int nslots = m.pprefix[kTB * kTB];
+    for_each_target<true, kPBlock>(nslots, tid, tid, [&](auto shared_c, int u, int sub, int k) {
+      constexpr bool SHARED = decltype(shared_c)::value;
+      const PairSlot ps = pair_slot(m, u);
+      const int srow = ps.srow, lx = ps.lx;
+      const bool two = ps.two;
+      const float4 r0 = qrec[ps.g];
+      const float4 r1 = qrec[ps.g + (two ? 1 : 0)];
+      const float two_hh = 2.0f * c.inv_hh;
+      const float x0 = r0.x - ox, y0 = r0.y - oy, z0 = r0.z - oz, x1 = r1.x - ox, y1 = r1.y - oy, z1 = r1.z - oz;
+      const float sx0 = two_hh * x0, sy0 = two_hh * y0, sz0 = two_hh * z0;
+      const float sx1 = two_hh * x1, sy1 = two_hh * y1, sz1 = two_hh * z1;
+      const float a00 = 1.0f - c.inv_hh * __builtin_fmaf(z0, z0, __builtin_fmaf(y0, y0, x0 * x0));
+      const float a01 = two ? 1.0f - c.inv_hh * __builtin_fmaf(z1, z1, __builtin_fmaf(y1, y1, x1 * x1)) : -1.0e30f;
+      float acc[2] = {0.0f, 0.0f}, accb[2] = {0.0f, 0.0f};
+      auto sweep_run = [&](int rr) {
+        int j, je;
+        tile_run(m, rr, lx, j, je);
+        auto test4 = [&](int jj) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float4 cnd = A[jj + v];
+            const float q0 = fma_clamp01(cnd.z, sz0, __builtin_fmaf(cnd.y, sy0, __builtin_fmaf(cnd.x, sx0, cnd.w + a00)));
+            const float q1 = fma_clamp01(cnd.z, sz1, __builtin_fmaf(cnd.y, sy1, __builtin_fmaf(cnd.x, sx1, cnd.w + a01)));
+            if (v & 1) {
+              accb[0] = __builtin_fmaf(q0, q0, accb[0]);
+              accb[1] = __builtin_fmaf(q1, q1, accb[1]);
+            } else {
+              acc[0] = __builtin_fmaf(q0, q0, acc[0]);
+              acc[1] = __builtin_fmaf(q1, q1, acc[1]);
+            }
+          }
+        };
+        for (; j + 4 < je; j += 8) {
+          test4(j);
+          test4(j + 4);
+        }
+        if (j < je) test4(j);
+      };
+      if constexpr (!SHARED) {
+#pragma unroll 1
+        for (int dz = -kTH; dz <= kTH; dz += kTH) {
+#pragma unroll 1
+          for (int dy = -1; dy <= 1; ++dy) sweep_run(srow + dz + dy);
+        }
+      } else {
+#pragma unroll 1
+        for (int ri = sub; ri < 9; ri += k) sweep_run(srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
+      }
+      acc[0] += accb[0];
+      acc[1] += accb[1];
+      if constexpr (SHARED) {
+        for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
+          acc[0] += __shfl_xor(acc[0], o, kWave);
+          acc[1] += __shfl_xor(acc[1], o, kWave);
+        }
+        if (sub != 0) return;
+      }
+      finish(__float_as_int(r0.w), __builtin_fmaf(acc[0], c.mass * c.A, c.W0));  // starts at W0, self included
+      if (two) finish(__float_as_int(r1.w), __builtin_fmaf(acc[1], c.mass * c.A, c.W0));
+    });
+  }
+  wave_atomic_max(&stats->pci_cur_err_bits, ebits);
+}
+
 }  // namespace dsl
