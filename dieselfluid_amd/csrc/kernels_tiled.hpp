@@ -844,11 +844,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
         self_term = (me.x == me.x && me.y == me.y && me.z == me.z) ? 1.0f : 0.0f;
         const float two_hh = 2.0f * c.inv_hh;
         const float sx = two_hh * me.x, sy = two_hh * me.y, sz = two_hh * me.z, a0 = 1.0f + me.w;
-#ifdef DSL_PROBE_PAIR
-        const float px2 = sx * 1.01f, py2 = sy * 0.99f, pz2 = sz * 1.02f, pa2 = a0 - 0.01f;
-        float pacc2 = 0.f, pacc3 = 0.f;
-        unsigned int pmask2 = 0u;
-#endif
         // one x-run of candidates (row rr of the staged tile, the 3 cells around the target's)
         auto sweep_run = [&](int ri, int rr) {
           int j, je;
@@ -868,12 +863,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
               mask_push(mask, q);
               if (u & 1) acc1 = __builtin_fmaf(q, q, acc1);
               else acc = __builtin_fmaf(q, q, acc);
-#ifdef DSL_PROBE_PAIR  // timing probe (r03): a second target's test on the same record -- what two targets per lane would cost
-              const float q2 = fma_clamp01(cnd.z, pz2, __builtin_fmaf(cnd.y, py2, __builtin_fmaf(cnd.x, px2, cnd.w + pa2)));
-              mask_push(pmask2, q2);
-              if (u & 1) pacc3 = __builtin_fmaf(q2, q2, pacc3);
-              else pacc2 = __builtin_fmaf(q2, q2, pacc2);
-#endif
             }
           };
           auto sweep_to = [&](int jend) {  // 8 candidates per trip while they last, then at most one block of 4
@@ -889,10 +878,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
           const int j32 = j + 32;
           sweep_to(min(je, j32));
           nmask[(size_t)ri * mstride + g] = mask;
-#ifdef DSL_PROBE_PAIR
-          nmask[(size_t)(kMaskHigh + ri) * mstride + g] = pmask2;  // (keeps the probe's second test alive)
-          pmask2 = 0u;
-#endif
           if (je > j32) {  // a second word for candidates 32-63 (rare: occupancy 8.3 +- 2 per cell once melted);
             mask = 0u;     // a run longer than 64 leaves garbage in it, its valid bit is clear
             sweep_to(je);
@@ -911,9 +896,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
           for (int ri = sub; ri < 9; ri += k) sweep_run(ri, srow + (ri / 3 - 1) * kTH + (ri % 3 - 1));
         }
         acc += acc1;
-#ifdef DSL_PROBE_PAIR
-        if (pacc2 + pacc3 == 12345.678f) acc += 1.0f;  // (keeps the probe's sums alive)
-#endif
       } else if (sub == 0) {
         const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
         for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
@@ -1744,21 +1726,6 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? *word_of(s, kMaskHigh) : 0u;
               };
               unsigned int ahead2 = second_of(0, rn, jn, jen);
-#ifdef DSL_DIAG_OLD_AHEAD  // (bisecting aid: the r02 form of this loop, one word ahead in a scalar)
-              unsigned int ahead = wq[0];
-#pragma unroll
-              for (int s = 0; s < 9; ++s) {
-                const unsigned int word = ahead, word2 = ahead2;
-                const int j = jn, je = jen, ri = rn;
-                if (s < 8) {
-                  rn = run_of(s + 1);
-                  if (runs_masked != 0u) ahead = *word_of(s + 1, 0);
-                  run_bounds_of_row(row_of(s + 1), jn, jen);
-                  ahead2 = second_of(s + 1, rn, jn, jen);
-                }
-                walk_run(ri, j, je, word, word2);
-              }
-#else
               // (r03, measured and removed: a two-run WINDOW for the developed flow -- the wave walks run s until every lane
               // is through with it, but a lane without bits left in run s takes bits of its run s+1 meanwhile, second words
               // as steps 9..17 of the same window -- because there the busiest lane of EACH run sets the pace: 7.7e8 VALU
@@ -1778,7 +1745,6 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 }
                 walk_run(ri, j, je, word, word2);
               }
-#endif
             } else {
 #pragma unroll 1
               for (int ri = sub; ri < 9; ri += k) {
