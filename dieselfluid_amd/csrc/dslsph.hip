@@ -88,6 +88,10 @@ struct dsl_handle {
   int64_t pci_steps = 0;  // completed steps since dsl_pcisph_begin
   int *qcount = nullptr, *qstart = nullptr, *qsums = nullptr;
   int *qtiles = nullptr, *n_qtiles = nullptr, *qtile_desc = nullptr;  // FAST: the tiles that hold queries and their tables
+  // FAST, two queries per lane: kQueryRow record slots per grid cell instead of the sorted array (no prefix scan, no
+  // scatter pass: kernels_tiled.hpp, tile_setup_load_counts); DSL_PCI_QROWS=0, or an allocation that fails, keeps the array
+  float4* qrows = nullptr;
+  bool pci_qrows = true;
   float4* qrec = nullptr;
   unsigned int* pci_drift = nullptr;
   unsigned int* pci_drift_host = nullptr;  // pinned: the snapshot of the counters the next look reads
@@ -771,6 +775,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->qtiles);
   (void)hipFree(h->n_qtiles);
   (void)hipFree(h->qtile_desc);
+  (void)hipFree(h->qrows);
   (void)hipFree(h->pci_drift);
   if (h->pci_drift_host) (void)hipHostFree(h->pci_drift_host);
   if (h->ev_drift) (void)hipEventDestroy(h->ev_drift);
@@ -833,6 +838,14 @@ int alloc_query_bins(dsl_handle* h) {
     if (!h->qtiles && (rc = dev_alloc(h, &h->qtiles, (size_t)h->tg.ntiles))) return rc;
     if (!h->n_qtiles && (rc = dev_alloc(h, &h->n_qtiles, (size_t)8))) return rc;
     if (!h->qtile_desc && (rc = dev_alloc(h, &h->qtile_desc, (size_t)std::min(h->tg.ntiles, h->cap) * kMetaInts))) return rc;
+    if (h->pci_qrows && h->pci_qpair && h->pci_qtiled && !h->qrows) {
+      // 512 bytes per grid cell (2.1 GB for the 4M scene's 4.1M cells, 33 GB for the 64M scene's -- of 288), touched where queries are
+      if (dev_alloc(h, &h->qrows, (size_t)h->ncell * kQueryRow) != DSL_OK) {
+        h->qrows = nullptr;
+        h->pci_qrows = false;
+        h->err.clear();
+      }
+    }
   }
   return DSL_OK;
 }
@@ -975,6 +988,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   if (const char* e = std::getenv("DSL_DENSITY_PAIR")) h->density_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_QTILED")) h->pci_qtiled = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_QPAIR")) h->pci_qpair = std::atoi(e) != 0;
+  if (const char* e = std::getenv("DSL_PCI_QROWS")) h->pci_qrows = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_BINNED")) {  // -1 never, 0 automatic, 1 always (dsl_pcisph_set_binning)
     const int m = std::atoi(e);
     h->pci_bin_mode = m < 0 ? -1 : (m > 0 ? 1 : 0);
@@ -1634,7 +1648,20 @@ int pci_iterate(dsl_handle* h) {
     // cells, then the sweep in that order (kernels_sph.hpp: k_pci_predict_bin)
     if (int rc = alloc_query_bins(h)) return rc;
     CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
+    const bool qtiled = tiled && h->pci_qtiled;
+    const bool rows = qtiled && h->pci_qpair && h->pci_qrows && h->qrows != nullptr;
+    if (rows) HIP_TRY(h, hipMemsetAsync(h->n_qtiles, 0, 2 * sizeof(int), h->stream));  // [0] tile list length, [1] spilled queries
     int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
+      if (rows) {
+        hipLaunchKernelGGL((k_pci_predict_bin<false, true, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
+                           h->qcount, nullptr, nullptr, nullptr, h->dcounter + 4, h->press, h->dstats, h->qrows, kQueryRow,
+                           h->qrec, h->n_qtiles + 1);
+        hipLaunchKernelGGL(k_qtile_list<true>, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->qcount,
+                           h->qtiles, h->n_qtiles, h->dstats);
+        hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, c, h->tg,
+                           h->cell_start, nullptr, h->qtiles, h->n_qtiles, h->qtile_desc, h->qcount);
+        return;
+      }
       if (tiled)
         hipLaunchKernelGGL((k_pci_predict_bin<false, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
                            h->qcount, h->rank, h->n_qtiles, nullptr, h->dcounter + 4, h->press, h->dstats);
@@ -1646,8 +1673,8 @@ int pci_iterate(dsl_handle* h) {
       hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, nullptr, nullptr);
       hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, h->qstart, nullptr);
       hipLaunchKernelGGL(k_pci_query_scatter, g, b, 0, h->stream, c, cpp, h->rank, h->qstart, h->qrec, h->dstats);
-      if (tiled && h->pci_qtiled) {  // the tiles that hold queries, and their tables
-        hipLaunchKernelGGL(k_qtile_list, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->qstart,
+      if (qtiled) {  // the tiles that hold queries, and their tables
+        hipLaunchKernelGGL(k_qtile_list<false>, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->qstart,
                            h->qtiles, h->n_qtiles, h->dstats);
         hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, c, h->tg,
                            h->cell_start, h->qstart, h->qtiles, h->n_qtiles, h->qtile_desc);
@@ -1655,9 +1682,17 @@ int pci_iterate(dsl_handle* h) {
     });
     if (rc) return rc;
     rc = timed(h, DSL_K_PCI_DENSITY, [&] {
-      if (tiled && h->pci_qtiled) {
+      if (rows) {
+        hipLaunchKernelGGL(k_pci_density_qpair<true>, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
+                           h->n_qtiles, h->qtile_desc, h->cell_start, p, h->qrows, h->press, h->dstats);
+        // the queries that found their cell's row full (a global-memory sweep over a short list; usually empty)
+        hipLaunchKernelGGL((k_pci_density_binned<true>), dim3(std::min(grid_for(launch_n(h)), 1024)), b, 0, h->stream, c,
+                           neigh(h), p, h->qrec, h->n_qtiles + 1, h->press, h->dstats);
+        return;
+      }
+      if (qtiled) {
         if (h->pci_qpair)  // two queries of one cell per lane (256-thread workgroups, four per CU)
-          hipLaunchKernelGGL(k_pci_density_qpair, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
+          hipLaunchKernelGGL(k_pci_density_qpair<false>, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
                              h->n_qtiles, h->qtile_desc, h->cell_start, p, h->qrec, h->press, h->dstats);
         else
           hipLaunchKernelGGL(k_pci_density_qtiled, dim3(persistent_grid(h, 2)), dim3(kTBlock), 0, h->stream, c, h->tg,
@@ -1666,7 +1701,7 @@ int pci_iterate(dsl_handle* h) {
       }
       by_math(h, [&](auto fast) {
         hipLaunchKernelGGL((k_pci_density_binned<decltype(fast)::value>), g, b, 0, h->stream, c, neigh(h), p, h->qrec,
-                           h->qstart, h->press, h->dstats);
+                           h->qstart + h->c.ncell, h->press, h->dstats);
       });
     });
     if (rc) return rc;

@@ -635,20 +635,27 @@ __device__ __forceinline__ void pci_drift_add(unsigned int* __restrict__ drift, 
 // grid around the box).  Such a query is finished here (density = W0, :76-92 on that value) instead of being clamped
 // into the grid's outermost cells with thousands of others: the predictor knows no walls, and by step 1500 of the 4M
 // scene four queries out of five are below the floor.
-template <bool GHOSTS, bool ADD_G, bool FAST>
+// ROWS (kernels_tiled.hpp: tile_setup_load_counts): the query's record goes straight into slot `rank` of its cell's row
+// of `row_slots` records (qrows), or, when the row is full, behind the spill list (spill, n_spill), which a
+// global-memory sweep finishes; qrank is then unused and n_qtiles is cleared by the host (the spill counter sits
+// next to it and is written by this very launch).
+template <bool GHOSTS, bool ADD_G, bool FAST, bool ROWS = false>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd, CSoa3 p, Soa3 pp, Soa3 pv, CSoa3 gterm,
                                                             Soa3 frc, int* __restrict__ qcount, int* __restrict__ qrank,
                                                             int* __restrict__ n_qtiles, unsigned int* __restrict__ drift,
                                                             const int* __restrict__ off_grid, float* __restrict__ press,
-                                                            DevStats* stats) {
+                                                            DevStats* stats, float4* __restrict__ qrows = nullptr,
+                                                            int row_slots = 0, float4* __restrict__ spill = nullptr,
+                                                            int* __restrict__ n_spill = nullptr) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i == 0 && n_qtiles != nullptr) *n_qtiles = 0;  // the length of this iteration's query-tile list (k_qtile_list)
+  if (!ROWS && i == 0 && n_qtiles != nullptr) *n_qtiles = 0;  // the length of this iteration's query-tile list (k_qtile_list)
   const int lane = threadIdx.x & (kWave - 1);
   const bool all_inside = *off_grid == 0;
   int cell = -1;
   bool left = false, mine = false;
   unsigned int err_bits = 0u;
+  float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
   // (the particle's own position is only read where something asks for it: slab ownership, the drift statistic)
   if (i < live_n(c) && !bnd.is(i) && (GHOSTS || c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i]))) {
     const float fx = frc.x[i], fy = frc.y[i], fz = frc.z[i];
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
       if (!GHOSTS || c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
     } else {
       cell = cell_of(c, qx, qy, qz);
+      rec = make_float4(qx, qy, qz, __int_as_float(i));
     }
   }
   // Equal-cell runs of consecutive lanes share one atomic (early on the queries of a cell's particles are still
@@ -704,7 +712,15 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
   int base = 0;
   if (lane == head_lane && cell >= 0) base = atomicAdd(&qcount[cell], next - head_lane);
   base = __shfl(base, head_lane, kWave);
-  if (i < live_n(c)) qrank[i] = cell >= 0 ? base + (lane - head_lane) : -1;
+  if constexpr (ROWS) {
+    if (cell >= 0) {
+      const int r = base + (lane - head_lane);
+      if (r < row_slots) qrows[(size_t)cell * row_slots + r] = rec;
+      else spill[atomicAdd(n_spill, 1)] = rec;  // (rare: more queries in one cell than a row holds)
+    }
+  } else {
+    if (i < live_n(c)) qrank[i] = cell >= 0 ? base + (lane - head_lane) : -1;
+  }
   if (drift != nullptr) pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
   wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
 }
@@ -723,14 +739,15 @@ __global__ __launch_bounds__(kBlock) void k_pci_query_scatter(DevConsts c, CSoa3
 }
 
 // DF + pressure accumulate :76-92 for query record k (k_pci_density's body; the query comes from its record)
+// (`count`: the number of records -- the query prefix's last entry, or the spill counter of the query rows; grid-stride)
 template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_pci_density_binned(DevConsts c, Neigh nb, CSoa3 p, const float4* __restrict__ qrec,
-                                                               const int* __restrict__ qstart, float* __restrict__ press,
+                                                               const int* __restrict__ count, float* __restrict__ press,
                                                                DevStats* stats) {
   if (stats->pci_done) return;
-  const int k = blockIdx.x * kBlock + threadIdx.x;
   unsigned int err_bits = 0u;
-  if (k < qstart[c.ncell]) {
+  const int n = *count;
+  for (int k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
     const float4 rec = qrec[k];
     const int i = __float_as_int(rec.w);
     const float xi = rec.x, yi = rec.y, zi = rec.z;
@@ -755,7 +772,10 @@ __global__ __launch_bounds__(kBlock) void k_pci_density_binned(DevConsts c, Neig
     const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
     const float dp = density_error * c.delta;
     press[i] += dp;
-    if (c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
+    if (c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i])) {
+      const unsigned int eb = nonneg_bits(abs_err);
+      err_bits = eb > err_bits ? eb : err_bits;
+    }
   }
   wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
 }

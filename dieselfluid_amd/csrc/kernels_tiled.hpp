@@ -233,6 +233,40 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
     }
   }
 }
+// Query ROWS (PCISPH, binned queries, FAST): every grid cell owns kQueryRow record slots, a query takes slot
+// atomicAdd(count[cell]) of its cell's row -- no prefix scan and no scatter pass between the predictor and the sweep.
+// A tile's target table is then made of its cells' COUNTS: lane r builds the pseudo prefix 0, c1, c1+c2, ... of staged
+// row r's four interior cells (the same shape tile_setup_load gives the particles' table) and leaves the counts zero
+// for the next iteration -- every cell with a count belongs to exactly one listed tile.
+constexpr int kQueryRow = 32;
+__device__ __forceinline__ void tile_setup_load_counts(const DevConsts& c, const TileGrid& tg, int tile,
+                                                       int* __restrict__ qcount, TileSetupRegs& r) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k <= kTH; ++k) r.s[k] = 0;
+  if (tid >= kTRows) return;
+  const int tx = tile % tg.tnx, ty = (tile / tg.tnx) % tg.tny, tz = tile / (tg.tnx * tg.tny);
+  const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
+  const int ry = tid % kTH, rz = tid / kTH;
+  const int y = ty * kTB - 1 + ry, z = tz * kTB - 1 + rz;
+  if (ry >= 1 && ry <= kTB && rz >= 1 && rz <= kTB && y < ny && z < nz) {
+    const int row = (z * ny + y) * nx;
+    int cnt[kTB];
+#pragma unroll
+    for (int k = 0; k < kTB; ++k) {
+      const int x = tx * kTB + k;
+      cnt[k] = x < nx ? qcount[row + x] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kTB; ++k) {
+      const int x = tx * kTB + k;
+      if (cnt[k] != 0) qcount[row + x] = 0;
+      r.s[k + 2] = r.s[k + 1] + min(cnt[k], kQueryRow);
+    }
+    r.s[kTH] = r.s[kTB + 1];
+  }
+}
+
 // One wave per non-empty tile (tile list 0): the tile's table, written where the sweeping kernels
 // pick it up.  ~31k tiles x 1.5 KB at 16M particles.  Lane r holds staged row r; the two prefix sums
 // run over the lanes (no LDS, no barrier), every lane writes its own row's entries.
@@ -242,7 +276,8 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
 __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                      const int* __restrict__ target_start,
                                                      const int* __restrict__ tiles, const int* __restrict__ n_tiles,
-                                                     int* __restrict__ desc) {
+                                                     int* __restrict__ desc, int* __restrict__ query_counts = nullptr) {
+  // (query_counts != nullptr: query rows, see tile_setup_load_counts; target_start is then unused)
   const int n = *n_tiles;
   const int lane = threadIdx.x;
   const int ry = lane % kTH, rz = lane / kTH;
@@ -275,7 +310,13 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
         const int ir = (rz - 1) * kTB + (ry - 1), t0 = tinc - tv;  // the row's first target
         out->tprefix[ir] = t0;
         out->pprefix[ir] = pinc - pv;
-        out->trow[ir] = make_int4(q.s[1] - t0, lds0 + (r.s[1] - r.s[0]) - t0,
+        // (query rows: .x = the grid cell of the row's first interior cell -- a record is named by its cell and its
+        // place in the cell's row)
+        int first = q.s[1] - t0;
+        if (query_counts != nullptr)
+          first = (((tile / (tg.tnx * tg.tny)) * kTB + rz - 1) * c.dims[1] + ((tile / tg.tnx) % tg.tny) * kTB + ry - 1) * c.dims[0] +
+                  (tile % tg.tnx) * kTB;
+        out->trow[ir] = make_int4(first, lds0 + (r.s[1] - r.s[0]) - t0,
                                   (t0 + (q.s[2] - q.s[1])) | ((t0 + (q.s[3] - q.s[1])) << 16), t0 + (q.s[4] - q.s[1]));
       }
       if (lane == kTRows - 1) {  // (the last interior row is lane 28: this lane's inclusive sums are the totals)
@@ -300,7 +341,13 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
     TileSetupRegs r, r2;
     tile_setup_load(c, tg, tile, cell_start, r);
     if (two) tile_setup_load(c, tg, tile2, cell_start, r2);
-    if (queries) {
+    if (query_counts != nullptr) {
+      TileSetupRegs q, q2;
+      tile_setup_load_counts(c, tg, tile, query_counts, q);
+      if (two) tile_setup_load_counts(c, tg, tile2, query_counts, q2);
+      table(item, tile, r, q);
+      if (two) table(item2, tile2, r2, q2);
+    } else if (queries) {
       TileSetupRegs q, q2;
       tile_setup_load(c, tg, tile, target_start, q);
       if (two) tile_setup_load(c, tg, tile2, target_start, q2);
@@ -315,6 +362,8 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
 
 // the tiles that hold at least one QUERY (PCISPH with binned queries): one list, in the boxed order of k_tile_list;
 // the list's length is cleared by k_pci_predict_bin at the head of the iteration
+// (ROWS: `qstart` is the query COUNT per cell, see tile_setup_load_counts)
+template <bool ROWS>
 __global__ __launch_bounds__(kBlock) void k_qtile_list(DevConsts c, TileGrid tg, const int* __restrict__ qstart,
                                                        int* __restrict__ qtiles, int* __restrict__ n_qtiles,
                                                        const DevStats* stats) {
@@ -334,7 +383,12 @@ __global__ __launch_bounds__(kBlock) void k_qtile_list(DevConsts c, TileGrid tg,
         const int z = tz * kTB + dz, y = ty * kTB + dy;
         if (z < nz && y < ny) {
           const int row = (z * ny + y) * nx;
-          cnt += qstart[row + xb] - qstart[row + xa];
+          if constexpr (ROWS) {
+#pragma unroll
+            for (int k = 0; k < kTB; ++k) cnt += xa + k < nx ? qstart[row + xa + k] : 0;
+          } else {
+            cnt += qstart[row + xb] - qstart[row + xa];
+          }
         }
       }
   }
@@ -1020,6 +1074,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
 constexpr int kPBlock = 256;
 struct PairSlot {
   int srow, lx, g, own;  // staged row and tile-local x cell of the slot's cell; global slot and LDS record of its first target
+  int rowbase, j;        // trow[ir].x and the first target's place inside its cell (query rows: k_pci_density_qpair)
   bool two;              // the slot holds two targets (g + 1, own + 1 is the second)
 };
 __device__ __forceinline__ PairSlot pair_slot(const TileMeta& m, int u) {
@@ -1046,6 +1101,8 @@ __device__ __forceinline__ PairSlot pair_slot(const TileMeta& m, int u) {
   r.lx = lx;
   r.g = w.x + t0;
   r.own = w.y + t0;
+  r.rowbase = w.x;
+  r.j = 2 * q;
   r.two = t0 + 1 < end;
   return r;
 }
@@ -2291,6 +2348,8 @@ __global__ __launch_bounds__(kTBlock) void k_pci_density_qtiled(DevConsts c, Til
 // what makes this possible for DensityF: the un-binned kernel's targets are the particles of a cell, whose query points
 // the reference never brings back to that cell.  A slot is two queries of one cell or a cell's odd one out
 // (TileMeta::pprefix, here over the QUERY counts); short last passes are shared out among 2 .. 16 lanes per slot.
+// ROWS: the records live in per-cell rows of kQueryRow slots (tile_setup_load_counts) instead of one sorted array.
+template <bool ROWS>
 __global__ __launch_bounds__(kPBlock, 4) void k_pci_density_qpair(DevConsts c, TileGrid tg, const int* __restrict__ n_qtiles,
                                                                  const int* __restrict__ desc, const int* __restrict__ cell_start,
                                                                  CSoa3 p, const float4* __restrict__ qrec,
@@ -2373,7 +2432,15 @@ __global__ __launch_bounds__(kPBlock, 4) void k_pci_density_qpair(DevConsts c, T
         ir += (t >= m.tprefix[ir + 4]) ? 4 : 0;
         ir += (t >= m.tprefix[ir + 2]) ? 2 : 0;
         ir += (t >= m.tprefix[ir + 1]) ? 1 : 0;
-        const float4 rec = qrec[m.trow[ir].x + t];
+        const int4 w = m.trow[ir];
+        size_t at = (size_t)(w.x + t);
+        if constexpr (ROWS) {  // (at most 64 x kQueryRow targets: the 16-bit cell boundaries are valid)
+          const int b2 = w.z & 0xffff, b3 = (int)((unsigned)w.z >> 16), b4 = w.w;
+          const int lx = (t >= b2 ? 1 : 0) + (t >= b3 ? 1 : 0) + (t >= b4 ? 1 : 0);
+          const int begin = lx == 0 ? m.tprefix[ir] : (lx == 1 ? b2 : (lx == 2 ? b3 : b4));
+          at = (size_t)(w.x + lx) * kQueryRow + (t - begin);
+        }
+        const float4 rec = qrec[at];
         float density = c.W0;
         for_each_grid_candidate(c, cell_start, rec.x, rec.y, rec.z, [&](int j) {
           const float dx = rec.x - p.x[j], dy = rec.y - p.y[j], dz = rec.z - p.z[j];
@@ -2393,8 +2460,9 @@ __global__ __launch_bounds__(kPBlock, 4) void k_pci_density_qpair(DevConsts c, T
       const PairSlot ps = pair_slot(m, u);
       const int srow = ps.srow, lx = ps.lx;
       const bool two = ps.two;
-      const float4 r0 = qrec[ps.g];
-      const float4 r1 = qrec[ps.g + (two ? 1 : 0)];
+      const size_t at = ROWS ? (size_t)(ps.rowbase + lx - 1) * kQueryRow + ps.j : (size_t)ps.g;
+      const float4 r0 = qrec[at];
+      const float4 r1 = qrec[at + (two ? 1 : 0)];
       const float two_hh = 2.0f * c.inv_hh;
       const float x0 = r0.x - ox, y0 = r0.y - oy, z0 = r0.z - oz, x1 = r1.x - ox, y1 = r1.y - oy, z1 = r1.z - oz;
       const float sx0 = two_hh * x0, sy0 = two_hh * y0, sz0 = two_hh * z0;
