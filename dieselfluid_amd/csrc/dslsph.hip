@@ -382,10 +382,16 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   // spot when none does)
   if (h->pci_active) HIP_TRY(h, hipMemsetAsync(h->dcounter + 4, 0, sizeof(int), h->stream));
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
-    hipLaunchKernelGGL(k_cell_rank, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
-                       ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
-                       onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
-                       ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->pci_active ? h->dcounter + 4 : nullptr);
+    if (h->pci_active)
+      hipLaunchKernelGGL(k_cell_rank<true>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
+                         ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
+                         onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
+                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->dcounter + 4);
+    else
+      hipLaunchKernelGGL(k_cell_rank<false>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
+                         ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
+                         onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
+                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {

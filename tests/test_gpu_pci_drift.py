@@ -143,12 +143,13 @@ def test_binned_density_matches_a_float64_brute_force_after_the_drift():
 @pytest.mark.parametrize("math_mode", [EXACT, FAST])
 def test_particles_outside_the_grid_keep_their_neighbours(math_mode):
     """The binned form finishes a query further than h outside the grid's bounds on the spot (no neighbour there) -- but
-    only while every PARTICLE lies inside them.  Here the grid stops half way up the fluid block: the particles above
-    are clamped into its top cells by the cell rule (in the oracle as well), and the queries up there, whole cells
-    outside the grid, must still find them."""
+    only while every PARTICLE lies inside them.  Here the grid stops a quarter of the way up the fluid block: the
+    particles above are clamped into its top cells by the cell rule (in the oracle as well), and the queries up there,
+    whole cells outside the grid, must still find them.  Those top cells hold ~44 particles and as many queries: more
+    than a cell's row of 32 query slots (the spill list) and more than a tile's LDS image (the global-memory sweep)."""
     from dieselfluid_amd import SPHEngine
     p, pos = _scene(12, math_mode)
-    p.grid_max[1] = p.grid_min[1] + 0.5 * (float(pos[:, 1].max()) - p.grid_min[1])
+    p.grid_max[1] = p.grid_min[1] + 0.25 * (float(pos[:, 1].max()) - p.grid_min[1])
     assert (pos[:, 1] > p.grid_max[1] + 2 * p.h).sum() > 100
     frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (pos.shape[0], 1))
     res = []
