@@ -15,7 +15,7 @@ pmc_sets=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY S
           "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE")
 profile() {  # profile <tag> <steps> <bench args...>   (bench.py's exact / developed segments are switched off here)
   local tag=$1 steps=$2; shift 2
-  local cmd="python3 $R/bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 $*"
+  local cmd="python3 $R/bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 --drift-steps 0 $*"
   rm -rf /tmp/prof_${tag}_stats
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${tag}_stats -- $cmd --steps 20 --warmup 5 > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_stats.err
   cp $(find /tmp/prof_${tag}_stats -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats.csv
@@ -33,7 +33,12 @@ profile wcsph16m 3
 profile pcisph4m 3 --method pcisph --n3 160
 cd $R
 timeout -k 10 400 python bench.py --method pcisph --n3 160 --steps 20 --warmup 5 --no-cpu-baseline > $out/pcisph_4m_bench.json 2> $out/pcisph_4m.err; echo "pcisph 4m rc=$?"
-timeout -k 10 600 python bench.py --method pcisph --n3 400 --extra-terms --steps 10 --warmup 3 --no-cpu-baseline > $out/pcisph_64m_xsph_cohesion_bench.json 2> $out/pcisph_64m.err; echo "pcisph 64m rc=$?"
+timeout -k 10 600 python bench.py --method pcisph --n3 400 --extra-terms --steps 10 --warmup 3 --no-cpu-baseline --drift-steps 200 > $out/pcisph_64m_xsph_cohesion_bench.json 2> $out/pcisph_64m.err; echo "pcisph 64m rc=$?"
+# the 4M PCISPH scene over 1500 steps (the predictor drifts away from the particles; the queries get bins of their own)
+timeout -k 10 400 python tools/pci_long_run.py 160 1500 100 > $out/pcisph_4m_long_run.jsonl 2> $out/pcisph_4m_long_run.err; echo "pcisph long run rc=$?"
+# kernel trace of 20 binned steps from the state after 400 steps
+timeout -k 10 300 python tools/pci_drifted_state.py save 160 400 /tmp/pci400.npz > /dev/null
+(cd /tmp && rm -rf /tmp/prof_pcidrift && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pcidrift -- python3 $R/tools/pci_drifted_state.py run /tmp/pci400.npz 20 1 > $out/pcisph_4m_drifted_step400_run.json 2> $out/pcisph_4m_drifted.err; cp $(find /tmp/prof_pcidrift -name "*kernel_stats.csv" | head -1) $out/pcisph_4m_drifted_step400_kernel_stats.csv); echo "pcisph drifted trace rc=$?"
 timeout -k 10 300 python bench.py --n3 100 --steps 50 --warmup 10 --no-cpu-baseline --developed-steps 0 > $out/wcsph_1m_bench.json 2>/dev/null; echo "1m rc=$?"
 timeout -k 10 300 python bench.py --n3 400 --steps 10 --warmup 3 --no-cpu-baseline --developed-steps 0 > $out/wcsph_64m_bench.json 2>/dev/null; echo "64m rc=$?"
 timeout -k 10 300 python bench.py --math exact --steps 5 --warmup 2 --no-cpu-baseline --developed-steps 0 > $out/wcsph_16m_exact_bench.json 2>/dev/null; echo "exact rc=$?"
