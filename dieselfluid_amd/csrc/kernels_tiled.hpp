@@ -1774,8 +1774,14 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
 #pragma unroll
               for (int s = 0; s < 9; ++s) wq[s] = 0u;
               wq[0] = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);  // (not behind runs_masked)
+#ifndef DSL_FORCE_TRIPLE
+#define DSL_FORCE_TRIPLE 1
+#endif
+              constexpr bool kTripleRuns = DSL_FORCE_TRIPLE && SHARE && !EXACT && !WANT_XS && kMaskAhead >= 8;
+              // (three runs per loop, below: the last three words are requested while the first three runs are walked)
+              constexpr int kPreload = kTripleRuns ? 5 : kMaskAhead;
 #pragma unroll
-              for (int s = 1; s <= kMaskAhead && s < 9; ++s)
+              for (int s = 1; s <= kPreload && s < 9; ++s)
                 if (runs_masked != 0u) wq[s] = *word_of(s, 0);
               int jn, jen;
               run_bounds_of_row(row_of(0), jn, jen);
@@ -1789,6 +1795,98 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               // instructions per launch against 4.4e8 on the lattice, ~80 pair iterations per target for ~36 neighbours
               // (profiles/r03_developed_pmc.txt).  Two cursors cost five more VALU per pair and the window moves through
               // 18 steps: force 1.56 ms with it, 1.40 without.)
+              // Developed flow (the pass-sharing instantiation): THREE runs per wave-synchronised loop.  The wave spends on
+              // every loop as many trips as its busiest lane has bits -- ~9 per run for a mean of 4 once the lattice has
+              // melted, 80 pair trips per target for 36 neighbours -- and the busiest lane of a z-plane's three runs together
+              // is much closer to the mean than three busiest lanes one after the other; six loop set-ups (and their odd
+              // all-pad pairs) per target go as well.  A lane moves to its next non-empty word inside the loop (a three-
+              // deep queue of (word, top record): six more VALU per pair).  A lattice has nothing to gain (41 trips for 33
+              // neighbours) and keeps the loop per run.
+              if constexpr (kTripleRuns) {
+                auto walk3 = [&](unsigned int mm, int top, unsigned int n1, int tp1, unsigned int n2, int tp2) {
+                  // empty words to the back, so that one shift per exhausted word is enough
+                  if (n1 == 0u) {
+                    n1 = n2;
+                    tp1 = tp2;
+                    n2 = 0u;
+                  }
+                  if (mm == 0u) {
+                    mm = n1;
+                    top = tp1;
+                    n1 = n2;
+                    tp1 = tp2;
+                    n2 = 0u;
+                  }
+                  auto take = [&]() {
+                    const bool has = mm != 0u;
+                    const int idx = has ? top - __builtin_ctz(mm) : pad_rec;
+                    mm &= mm - 1u;
+                    if (mm == 0u) {
+                      mm = n1;
+                      top = tp1;
+                      n1 = n2;
+                      tp1 = tp2;
+                      n2 = 0u;
+                    }
+                    return idx;
+                  };
+                  if (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
+                    PairRec pr = fetch(take());
+                    bool more;
+                    do {
+                      const PairRec q = fetch(take());
+                      accum(pr);
+                      more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
+                      pr = fetch(take());
+                      accum(q);
+                    } while (more);
+                  }
+                };
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                  int jj[3], jje[3], rr[3];
+                  unsigned int ww[3], w2[3];
+                  bool unmasked = false, longrun = false;
+#pragma unroll
+                  for (int u = 0; u < 3; ++u) {
+                    const int s = 3 * g3 + u;
+                    rr[u] = run_of(s);
+                    run_bounds_of_row(row_of(s), jj[u], jje[u]);
+                    ww[u] = wq[s];
+                    if (g3 == 0 && runs_masked != 0u) wq[s + 6] = *word_of(s + 6, 0);
+                    w2[u] = second_of(s, rr[u], jj[u], jje[u]);  // (requested here, used behind the first words' walk)
+                    unmasked |= !((runs_masked >> rr[u]) & 1u);
+                    longrun |= jje[u] - jj[u] > 32;
+                  }
+                  if (__builtin_amdgcn_ballot_w64(unmasked) == 0ull) {
+                    {
+                      int tp[3];
+#pragma unroll
+                      for (int u = 0; u < 3; ++u) tp[u] = jj[u] + ((min(jje[u] - jj[u], 32) + 3) & ~3) - 1;
+                      walk3(ww[0], tp[0], ww[1], tp[1], ww[2], tp[2]);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(longrun) != 0ull) {  // candidates 32-63 of the three runs
+                      // (the runs' bounds are read again rather than kept alive through the walk above: registers)
+                      int tp[3];
+#pragma unroll
+                      for (int u = 0; u < 3; ++u) {
+                        int j2, je2;
+                        run_bounds_of_row(row_of(3 * g3 + u), j2, je2);
+                        tp[u] = j2 + 32 + ((min(je2 - j2 - 32, 32) + 3) & ~3) - 1;
+                      }
+                      walk3(w2[0], tp[0], w2[1], tp[1], w2[2], tp[2]);
+                    }
+                  } else {  // (a run without a mask -- longer than 64 candidates -- somewhere in the wave: run by run)
+#pragma unroll 1
+                    for (int u = 0; u < 3; ++u) {
+                      const int uu = u;
+                      walk_run(uu == 0 ? rr[0] : (uu == 1 ? rr[1] : rr[2]), uu == 0 ? jj[0] : (uu == 1 ? jj[1] : jj[2]),
+                               uu == 0 ? jje[0] : (uu == 1 ? jje[1] : jje[2]), uu == 0 ? ww[0] : (uu == 1 ? ww[1] : ww[2]),
+                               uu == 0 ? w2[0] : (uu == 1 ? w2[1] : w2[2]));
+                    }
+                  }
+                }
+              } else {
 #pragma unroll
               for (int s = 0; s < 9; ++s) {
                 const unsigned int word = wq[s], word2 = ahead2;
@@ -1801,6 +1899,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                   ahead2 = second_of(s + 1, rn, jn, jen);
                 }
                 walk_run(ri, j, je, word, word2);
+              }
               }
             } else {
 #pragma unroll 1
