@@ -1779,7 +1779,12 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
 #endif
               // (not the slab instantiations: they have no lattice twin to fall back on, and on a lattice the queue costs
               // a middle rank of 16M / 8 one per cent -- 0.455 against 0.450 ms per step)
-              constexpr bool kTripleRuns = DSL_FORCE_TRIPLE && SHARE && !SLAB && !EXACT && !WANT_XS && kMaskAhead >= 8;
+              // (EXACT: a lane still meets its candidates run by run, earliest first -- the reference's order, so the same
+              // bits -- and at ~150 VALU instructions per pair the queue is cheap: the lattice gains there too)
+#ifndef DSL_FORCE_TRIPLE_EXACT
+#define DSL_FORCE_TRIPLE_EXACT 1
+#endif
+              constexpr bool kTripleRuns = DSL_FORCE_TRIPLE && (SHARE || (EXACT && DSL_FORCE_TRIPLE_EXACT)) && !SLAB && !WANT_XS && kMaskAhead >= 8;
               // (three runs per loop, below: the last three words are requested while the first three runs are walked)
               constexpr int kPreload = kTripleRuns ? 5 : kMaskAhead;
 #pragma unroll
@@ -1821,8 +1826,15 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                   }
                   auto take = [&]() {
                     const bool has = mm != 0u;
-                    const int idx = has ? top - __builtin_ctz(mm) : pad_rec;
-                    mm &= mm - 1u;
+                    int idx;
+                    if constexpr (EXACT) {  // highest bit = earliest candidate first: the reference's order
+                      const int b = 31 - __builtin_clz(mm | 1u);
+                      idx = has ? top - b : pad_rec;
+                      mm = has ? (mm & ~(1u << b)) : 0u;
+                    } else {
+                      idx = has ? top - __builtin_ctz(mm) : pad_rec;
+                      mm &= mm - 1u;
+                    }
                     if (mm == 0u) {
                       mm = n1;
                       top = tp1;
@@ -1860,7 +1872,9 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                     unmasked |= !((runs_masked >> rr[u]) & 1u);
                     longrun |= jje[u] - jj[u] > 32;
                   }
-                  if (__builtin_amdgcn_ballot_w64(unmasked) == 0ull) {
+                  // (EXACT: a run's candidates 32-63 have to follow its first 32 directly -- the reference's order -- so a
+                  // wave with such a run somewhere in this z-plane takes the loop per run)
+                  if (__builtin_amdgcn_ballot_w64(unmasked || (EXACT && longrun)) == 0ull) {
                     {
                       int tp[3];
 #pragma unroll
