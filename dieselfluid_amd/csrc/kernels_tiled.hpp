@@ -806,8 +806,7 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
             const float mw = c.mass * w;
             density = density + mw;
           };
-#pragma unroll 1
-          for (int ri = 0; ri < 9; ++ri) {
+          auto run_by_run = [&](int ri) {
             const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
             int j, je;
             tile_run(m, rr, lx, j, je);
@@ -865,6 +864,101 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
                   add(qr, cq2);
                 } while (more);
               }
+            }
+          };
+          // Three runs per walk (the z-plane's, as in the force kernel): the candidate sweeps of the three runs first -- their
+          // mask words are what the force walk reads later anyway -- then ONE wave-synchronised loop over the set bits of
+          // all three, a lane taking its runs in order and each run's bits earliest candidate first: the reference's
+          // order, hence the same sum bit for bit, and the wave waits for the busiest lane of the plane once instead of
+          // three times.  A wave with a run of more than 32 candidates in the plane (its second chunk has to follow its
+          // first directly) keeps the loop per run.
+#pragma unroll 1
+          for (int g3 = 0; g3 < 3; ++g3) {
+            int jj[3], jje[3];
+            bool longrun = false;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              tile_run(m, srow + (g3 - 1) * kTH + (u - 1), lx, jj[u], jje[u]);
+              longrun |= jje[u] - jj[u] > 32;
+            }
+            if (__builtin_amdgcn_ballot_w64(longrun) != 0ull) {
+#pragma unroll 1
+              for (int u = 0; u < 3; ++u) run_by_run(3 * g3 + u);
+              continue;
+            }
+            unsigned int mk[3];
+            int tp[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              const int ri = 3 * g3 + u, j = jj[u], jend = jje[u];
+              mvalid |= 1u << ri;
+              unsigned int mask = 0u;
+              if (prefilter) {
+                for (int q4 = j; q4 < jend; q4 += 4) {
+#pragma unroll
+                  for (int v = 0; v < 4; ++v) {
+                    const float4 cnd = R[q4 + v];
+                    const float t = __builtin_fmaf(cnd.z, qsz, __builtin_fmaf(cnd.y, qsy, __builtin_fmaf(cnd.x, qsx, cnd.w + qa0)));
+                    mask_push_lt(mask, -1.0e-3f, t);
+                  }
+                }
+              } else {
+                for (int q4 = j; q4 < jend; q4 += 4) {
+#pragma unroll
+                  for (int v = 0; v < 4; ++v) {
+                    const float4 cnd = A[q4 + v];
+                    const float dx = me.x - cnd.x, dy = me.y - cnd.y, dz = me.z - cnd.z;
+                    mask_push_lt(mask, dist2<false>(dx, dy, dz), c.r2_thr);
+                  }
+                }
+              }
+              mask &= ~0u << ((4 - ((jend - j) & 3)) & 3);
+              nmask[(size_t)ri * mstride + g] = mask;
+              mk[u] = mask;
+              tp[u] = j + ((jend - j + 3) & ~3) - 1;  // record of bit 0
+            }
+            // the queue: empty words to the back, one shift per exhausted word
+            unsigned int mm = mk[0], n1 = mk[1], n2 = mk[2];
+            int top = tp[0], tp1 = tp[1], tp2 = tp[2];
+            if (n1 == 0u) {
+              n1 = n2;
+              tp1 = tp2;
+              n2 = 0u;
+            }
+            if (mm == 0u) {
+              mm = n1;
+              top = tp1;
+              n1 = n2;
+              tp1 = tp2;
+              n2 = 0u;
+            }
+            auto take = [&](bool& counts) {
+              const bool has = mm != 0u;
+              const int b = 31 - __builtin_clz(mm | 1u);  // highest set bit = earliest candidate
+              const int idx = has ? top - b : pad_rec;
+              mm = has ? (mm & ~(1u << b)) : 0u;
+              counts = has && idx != own;  // `if i != pIndex` (sph_field.go:164)
+              if (mm == 0u) {
+                mm = n1;
+                top = tp1;
+                n1 = n2;
+                tp1 = tp2;
+                n2 = 0u;
+              }
+              return idx;
+            };
+            if (__builtin_amdgcn_ballot_w64(mm != 0u) != 0ull) {
+              bool cp, cq;
+              float4 pr = A[take(cp)];
+              bool more;
+              do {
+                const float4 qr = A[take(cq)];
+                add(pr, cp);
+                more = __builtin_amdgcn_ballot_w64(mm != 0u) != 0ull;
+                const bool cq2 = cq;
+                pr = A[take(cp)];
+                add(qr, cq2);
+              } while (more);
             }
           }
           acc = density;
