@@ -1878,6 +1878,8 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
 #ifndef DSL_FORCE_TRIPLE_EXACT
 #define DSL_FORCE_TRIPLE_EXACT 1
 #endif
+              // (the FAST lattice instantiation, measured with it: force 0.86 -> 1.31 ms -- that one is compiled without a
+              // register cap and the queue pushes it past 128 VGPRs, one workgroup per CU)
               constexpr bool kTripleRuns = DSL_FORCE_TRIPLE && (SHARE || (EXACT && DSL_FORCE_TRIPLE_EXACT)) && !SLAB && !WANT_XS && kMaskAhead >= 8;
               // (three runs per loop, below: the last three words are requested while the first three runs are walked)
               constexpr int kPreload = kTripleRuns ? 5 : kMaskAhead;
