@@ -37,8 +37,9 @@ constexpr int kTCap = 2304;            // staged records per tile (1.33 x the 17
 constexpr float kFar = 1.0e15f;        // pad coordinate: finite, far outside any domain
 constexpr int kTileLists = 5;
 // per particle (SoA, stride = capacity): words 0-8 the masks of the 9 runs (first 32 candidates),
-// word 9 the valid bits, words 10-18 the masks of candidates 32-63 (written and read only for runs
-// that long)
+// words 10-18 the masks of candidates 32-63 (written and read only for runs that long).  Word 9 used to hold
+// "which runs have masks": that is a rule on the run's length (at most 64 candidates), which every reader
+// has from the tile table -- no longer written or read.
 constexpr int kMaskWords = 19;
 constexpr int kMaskValid = 9, kMaskHigh = 10;
 
@@ -768,7 +769,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
       const TileTarget tt = tile_target(m, t);
       const int srow = tt.srow, g = tt.g, lx = tt.lx;
       float acc = 0.0f, acc1 = 0.0f, self_term = 1.0f;
-      unsigned int mvalid = 0u;
       if constexpr (EXACT) {
         if (!ovf) {
           const int own = tt.own;
@@ -810,7 +810,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
             const int rr = srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
             int j, je;
             tile_run(m, rr, lx, j, je);
-            if (je - j <= 64) mvalid |= 1u << ri;
             if (!(j < je)) nmask[(size_t)ri * mstride + g] = 0u;  // an empty run still has a (read) mask word
             // chunks of up to 32 candidates: sweep -> mask word -> walk of its set bits, first candidate first
             for (int chunk = 0; j < je; ++chunk, j += 32) {
@@ -891,7 +890,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
               const int ri = 3 * g3 + u, j = jj[u], jend = jje[u];
-              mvalid |= 1u << ri;
               unsigned int mask = 0u;
               if (prefilter) {
                 for (int q4 = j; q4 < jend; q4 += 4) {
@@ -974,7 +972,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
             }
           });
         }
-        nmask[(size_t)kMaskValid * mstride + g] = mvalid;
         if (bnd.is(g)) {
           rho[g] = 0.0f;
           pterm[g] = __uint_as_float(0x7fc00000u);
@@ -996,7 +993,6 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
         auto sweep_run = [&](int ri, int rr) {
           int j, je;
           tile_run(m, rr, lx, j, je);
-          if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
           unsigned int mask = 0u;
 #ifdef DSL_DIAG_NO_SWEEP  // timing-only build: the per-tile fixed cost (set-up + staging + epilogue)
           je = j;
@@ -1059,12 +1055,10 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
       if constexpr (SHARED) {
         for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
           acc += __shfl_xor(acc, o, kWave);
-          mvalid |= __shfl_xor(mvalid, o, kWave);
         }
         if (sub != 0) return;
       }
       if (!ovf) acc = (acc - self_term) * (c.mass * c.A);  // the particle met itself once (q = 1)
-      nmask[(size_t)kMaskValid * mstride + g] = mvalid;
       if (bnd.is(g)) {  // a boundary particle reads as density 0, P/rho^2 = 0/0 (Bnd, sph_device.hpp)
         rho[g] = 0.0f;
         pterm[g] = __uint_as_float(0x7fc00000u);
@@ -1278,7 +1272,6 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
       const int srow = ps.srow, lx = ps.lx, g0 = ps.g;
       const bool two = ps.two;
       float acc[2] = {0.0f, 0.0f}, accb[2] = {0.0f, 0.0f}, self_term[2] = {1.0f, 1.0f};
-      unsigned int mvalid = 0u;
       if (!ovf) {
         const float4 me0 = A[ps.own];
         float4 me1 = A[ps.own + (two ? 1 : 0)];
@@ -1294,7 +1287,6 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
         auto sweep_run = [&](int ri, int rr) {
           int j, je;
           tile_run(m, rr, lx, j, je);
-          if (je - j <= 64) mvalid |= 1u << ri;  // else more candidates than mask bits: this run is swept in full
           unsigned int mask0 = 0u, mask1 = 0u;
           auto test4 = [&](int jj) {
 #pragma unroll
@@ -1370,7 +1362,6 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
         for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
           acc[0] += __shfl_xor(acc[0], o, kWave);
           acc[1] += __shfl_xor(acc[1], o, kWave);
-          mvalid |= __shfl_xor(mvalid, o, kWave);
         }
         if (sub != 0) return;
       }
@@ -1380,7 +1371,6 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
         const int g = g0 + e;
         float a = acc[e];
         if (!ovf) a = (a - self_term[e]) * (c.mass * c.A);  // the particle met itself once (q = 1)
-        nmask[(size_t)kMaskValid * mstride + g] = mvalid;
         if (bnd.is(g)) {  // a boundary particle reads as density 0, P/rho^2 = 0/0 (Bnd, sph_device.hpp)
           rho[g] = 0.0f;
           pterm[g] = __uint_as_float(0x7fc00000u);
@@ -1459,10 +1449,9 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     // The first pass's per-target mask words (valid word, first run word) are requested BEFORE the
     // staging loads, so that their latency passes under the staging wait instead of in front of the sweep.
     const int tperm = (tid & ~(kWave - 1)) + b128_group_slot(lane);
-    unsigned int pre_valid = 0u, pre_word = 0u;
+    unsigned int pre_word = 0u;
     if (!nolds && nmask != nullptr && tperm < m.tprefix[kTB * kTB]) {
       const int g0 = tile_target(m, tperm).g;
-      pre_valid = nmask[(size_t)kMaskValid * mstride + g0];
       pre_word = nmask[(size_t)(EXACT ? 0 : 4) * mstride + g0];  // the run visited first (FAST: the centre run, whatever the lane's mirroring)
     }
     DSL_STAMP(t1b);
@@ -1737,8 +1726,13 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               else accum_fast(rec);
             };
             const bool first_pass = !SHARED && t == tperm;  // (its mask words were requested before the staging)
-            const unsigned int runs_masked =
-                first_pass ? pre_valid : (nmask != nullptr ? nmask[(size_t)kMaskValid * mstride + g] : 0u);
+            // Which runs have mask words?  Those of at most 64 candidates -- a rule on the run's length, which this kernel
+            // reads off the same tile table the density sweep used, so the "valid" word the density kernels used to
+            // write per particle (and this kernel to fetch ahead of everything else) is gone: 8 B per particle of
+            // traffic and one load in the prologue; adding 8 B of mask traffic instead had cost the force kernel 3.7 %
+            // and the density kernel 1.2 % (profiles/README.md, r03).
+            const bool have_masks = nmask != nullptr;
+            auto run_masked = [&](int j, int je) { return have_masks && je - j <= 64; };
             DSL_STAMP(t4);
             DSL_STAMP_ADD(2, t3, t4);
             // Walk the in-range bits of one run (row rr of the staged tile, the 3 cells around the
@@ -1803,7 +1797,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             // wave has a run longer than that, this is all there is -- then, lane by lane, the chunks behind them
             // (the second mask word, or chunks of 32 with every bit set for a run without a mask).
             auto walk_run = [&](int ri, const int j, const int je, unsigned int first_word, unsigned int second_word) {
-              const bool has_mask = (runs_masked >> ri) & 1u;
+              const bool has_mask = run_masked(j, je);
               // (a run without a mask -- longer than 64 candidates, or no masks at all -- is rare: the selects
               // between a mask word and "every bit set" are only compiled into the path some lane needs them on)
               // (not in the XSPH / cohesion instantiations: they are at the register limit, a second copy of the walk spills)
@@ -1867,7 +1861,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               unsigned int wq[9];
 #pragma unroll
               for (int s = 0; s < 9; ++s) wq[s] = 0u;
-              wq[0] = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);  // (not behind runs_masked)
+              wq[0] = first_pass ? pre_word : (nmask != nullptr ? *word_of(0, 0) : 0u);
 #ifndef DSL_FORCE_TRIPLE
 #define DSL_FORCE_TRIPLE 1
 #endif
@@ -1885,11 +1879,11 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               constexpr int kPreload = kTripleRuns ? 5 : kMaskAhead;
 #pragma unroll
               for (int s = 1; s <= kPreload && s < 9; ++s)
-                if (runs_masked != 0u) wq[s] = *word_of(s, 0);
+                if (have_masks) wq[s] = *word_of(s, 0);
               int jn, jen;
               run_bounds_of_row(row_of(0), jn, jen);
               auto second_of = [&](int s, int ri, int j, int je) {
-                return (je - j > 32 && ((runs_masked >> ri) & 1u)) ? *word_of(s, kMaskHigh) : 0u;
+                return (je - j > 32 && run_masked(j, je)) ? *word_of(s, kMaskHigh) : 0u;
               };
               unsigned int ahead2 = second_of(0, rn, jn, jen);
               // (r03, measured and removed: a two-run WINDOW for the developed flow -- the wave walks run s until every lane
@@ -1963,9 +1957,9 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                     rr[u] = run_of(s);
                     run_bounds_of_row(row_of(s), jj[u], jje[u]);
                     ww[u] = wq[s];
-                    if (g3 == 0 && runs_masked != 0u) wq[s + 6] = *word_of(s + 6, 0);
+                    if (g3 == 0 && have_masks) wq[s + 6] = *word_of(s + 6, 0);
                     w2[u] = second_of(s, rr[u], jj[u], jje[u]);  // (requested here, used behind the first words' walk)
-                    unmasked |= !((runs_masked >> rr[u]) & 1u);
+                    unmasked |= !run_masked(jj[u], jje[u]);
                     longrun |= jje[u] - jj[u] > 32;
                   }
                   // (EXACT: a run's candidates 32-63 have to follow its first 32 directly -- the reference's order -- so a
@@ -2004,7 +1998,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
                 const unsigned int word = wq[s], word2 = ahead2;
                 const int j = jn, je = jen, ri = rn;
                 if (s + kMaskAhead + 1 < 9)
-                  if (runs_masked != 0u) wq[s + kMaskAhead + 1] = *word_of(s + kMaskAhead + 1, 0);
+                  if (have_masks) wq[s + kMaskAhead + 1] = *word_of(s + kMaskAhead + 1, 0);
                 if (s < 8) {
                   rn = run_of(s + 1);
                   run_bounds_of_row(row_of(s + 1), jn, jen);
@@ -2018,7 +2012,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
               for (int ri = sub; ri < 9; ri += k) {
                 int j, je;
                 run_bounds(ri, j, je);
-                const bool masked = (runs_masked >> ri) & 1u;
+                const bool masked = run_masked(j, je);
                 walk_run(ri, j, je, masked ? nmask[(size_t)ri * mstride + g] : 0u,
                          (masked && je - j > 32) ? nmask[(size_t)(kMaskHigh + ri) * mstride + g] : 0u);
               }
