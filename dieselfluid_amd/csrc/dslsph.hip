@@ -1574,6 +1574,10 @@ constexpr double kPciDriftFraction = 0.002;  // of the predicted positions outsi
 // how its steps were grouped into calls or on timing.
 int pci_drift_check(dsl_handle* h) {
   if (h->pci_bin_mode != 0 || h->pci_binned || h->lsh || h->pci_steps == 0 || h->pci_steps % kPciDriftPeriod != 0) return DSL_OK;
+  // (a host that is capturing this stream into a graph of its own gets no look: waiting for an event is not capturable,
+  // and a replayed graph could not change its kernels anyway -- such a host sets the mode with dsl_pcisph_set_binning)
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) return DSL_OK;
   if (h->drift_pending) {
     HIP_TRY(h, hipEventSynchronize(h->ev_drift));
     h->drift_pending = false;

@@ -255,7 +255,8 @@ int dsl_pcisph_error_word(dsl_handle *h, uint32_t *dev_word, int store);
  * query: DSL_MATH_EXACT results do not change by a bit).  mode 0 (default): switch when 0.2 % of the queries have left
  * their particle's 4x4x4-cell tile -- looked at every 4 steps through an asynchronous copy of the device's
  * counters that the next look reads (no stall; the decision trails the drift by 4 to 8 steps), a one-way switch until
- * the next dsl_pcisph_begin; 1: always; -1: never.  Environment DSL_PCI_BINNED presets the mode at dsl_create.
+ * the next dsl_pcisph_begin; 1: always; -1: never.  Environment DSL_PCI_BINNED presets the mode at dsl_create.  (While
+ * the handle's stream is being captured into a graph of the host's the automatic look is skipped: set the mode.)
  * dsl_pcisph_get_binning: the mode; whether the next correction iteration sorts its queries; and, slab mode (blocking
  * if asked for), whether a query point of an owned particle has drifted more than h beyond a slab plane since
  * dsl_pcisph_begin, i.e. out of what the 2h ghost band covers: from then on this rank's predicted densities -- the
