@@ -82,6 +82,9 @@ struct dsl_handle {
   // particle's tile (looked at every kPciDriftPeriod steps; a one-way latch until the next dsl_pcisph_begin), 1 = always,
   // -1 = never (dsl_pcisph_set_binning; DSL_PCI_BINNED presets it)
   int pci_bin_mode = 0;
+  int build_seq = 0;  // neighbour builds so far (k_cell_rank<true> stamps its off-grid flag with it)
+  bool pci_counters_clean = false;  // n_qtiles[0..1] are known to be zero (the first binned iteration clears them itself)
+  bool pci_iter_pending = false;  // DSL_PCI_ITERATE without its DSL_PCI_CHECK yet (the check clears the iteration's counters)
   bool pci_binned = false;
   bool pci_qpair = true;   // ... two queries per lane (DSL_PCI_QPAIR=0: one)
   bool pci_qtiled = true;  // FAST: sweep the binned queries tile by tile out of LDS (DSL_PCI_QTILED=0: the global-memory sweep)
@@ -378,20 +381,20 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   }
   h->sort_scratch_dirty = true;
   const bool onepass = h->scan_onepass;
-  // PCISPH: "a particle lies outside the grid's bounds" (dcounter[4]; k_pci_predict_bin finishes far-away queries on the
-  // spot when none does)
-  if (h->pci_active) HIP_TRY(h, hipMemsetAsync(h->dcounter + 4, 0, sizeof(int), h->stream));
+  // PCISPH: "a particle lies outside the grid's bounds" (dcounter[4] = the number of the last build that saw one;
+  // k_pci_predict_bin finishes far-away queries on the spot when this build saw none)
+  h->build_seq = h->build_seq == INT_MAX ? 1 : h->build_seq + 1;  // (never 0: the flag word starts zeroed)
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     if (h->pci_active)
       hipLaunchKernelGGL(k_cell_rank<true>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                          ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
                          onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
-                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->dcounter + 4);
+                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->dcounter + 4, h->build_seq);
     else
       hipLaunchKernelGGL(k_cell_rank<false>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                          ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
                          onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
-                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr);
+                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
@@ -1638,7 +1641,8 @@ int pci_begin_step(dsl_handle* h) {
   } else {
     if (int rc = viscous_pass(h, XS ? 1 : 0)) return rc;
   }
-  hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats);
+  hipLaunchKernelGGL(k_pci_reset, dim3(1), dim3(1), 0, h->stream, h->dstats, h->n_qtiles);
+  h->pci_iter_pending = false;
   HIP_TRY(h, hipGetLastError());
   return DSL_OK;
 }
@@ -1660,11 +1664,15 @@ int pci_iterate(dsl_handle* h) {
     CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
     const bool qtiled = tiled && h->pci_qtiled;
     const bool rows = qtiled && h->pci_qpair && h->pci_qrows && h->qrows != nullptr;
-    if (rows) HIP_TRY(h, hipMemsetAsync(h->n_qtiles, 0, 2 * sizeof(int), h->stream));  // [0] tile list length, [1] spilled queries
+    // n_qtiles[0] tile list length, [1] spilled queries: left at zero by k_pci_reset / k_pci_check (a memset node costs
+    // 7 us on the device, four per step); only a host that iterates twice without the check in between gets one here
+    if (rows && (h->pci_iter_pending || !h->pci_counters_clean)) HIP_TRY(h, hipMemsetAsync(h->n_qtiles, 0, 2 * sizeof(int), h->stream));
+    h->pci_counters_clean = true;
+    h->pci_iter_pending = true;
     int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
       if (rows) {
         hipLaunchKernelGGL((k_pci_predict_bin<false, true, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
-                           h->qcount, nullptr, nullptr, nullptr, h->dcounter + 4, h->press, h->dstats, h->qrows, kQueryRow,
+                           h->qcount, nullptr, nullptr, nullptr, h->dcounter + 4, h->build_seq, h->press, h->dstats, h->qrows, kQueryRow,
                            h->qrec, h->n_qtiles + 1);
         hipLaunchKernelGGL(k_qtile_list<true>, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->qcount,
                            h->qtiles, h->n_qtiles, h->dstats);
@@ -1674,11 +1682,11 @@ int pci_iterate(dsl_handle* h) {
       }
       if (tiled)
         hipLaunchKernelGGL((k_pci_predict_bin<false, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
-                           h->qcount, h->rank, h->n_qtiles, nullptr, h->dcounter + 4, h->press, h->dstats);
+                           h->qcount, h->rank, h->n_qtiles, nullptr, h->dcounter + 4, h->build_seq, h->press, h->dstats);
       else
         by_math(h, [&](auto fast) {
           hipLaunchKernelGGL((k_pci_predict_bin<true, false, decltype(fast)::value>), g, b, 0, h->stream, c, bnd_of(h), p, pp,
-                             pvv, cG, F, h->qcount, h->rank, nullptr, nullptr, h->dcounter + 4, h->press, h->dstats);
+                             pvv, cG, F, h->qcount, h->rank, nullptr, nullptr, h->dcounter + 4, h->build_seq, h->press, h->dstats);
         });
       hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, nullptr, nullptr);
       hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->qcount, h->qsums, h->qstart, nullptr);
@@ -1741,7 +1749,8 @@ int pci_iterate(dsl_handle* h) {
 }
 
 int pci_check(dsl_handle* h) {                   // :95-98
-  hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, h->c, h->dstats);
+  hipLaunchKernelGGL(k_pci_check, dim3(1), dim3(1), 0, h->stream, h->c, h->dstats, h->n_qtiles);
+  h->pci_iter_pending = false;
   HIP_TRY(h, hipGetLastError());
   return DSL_OK;
 }

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
                                                       int* __restrict__ rank, int* __restrict__ cell_count,
                                                       unsigned int* __restrict__ unordered, DevStats* stats,
                                                       int* __restrict__ n_tiles, int* __restrict__ cell_keys,
-                                                      int* __restrict__ overfull, int* __restrict__ off_grid) {
+                                                      int* __restrict__ overfull, int* __restrict__ off_grid,
+                                                      int build_seq) {
   const int i = blockIdx.x * kBlock + threadIdx.x;
   // the small counters of the later kernels of this build (the fullest-cell statistic of the scan, the tile-list
   // lengths): cleared here, at the head of the build, when the one-launch scan is in use (stats != nullptr)
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   if (i < n) {
     cell = sort_cell(c, px[i], py[i], pz[i]);
     if (ids) id = ids[i];
-    // PCISPH (off_grid != nullptr, cleared by the host in front of this launch): does any particle lie outside the
+    // PCISPH (OFF_GRID; the flag is never cleared: it holds the number of the last build that saw such a particle): does any particle lie outside the
     // grid's bounds, clamped into an outermost cell by the cell rule?  (false for NaN: that particle is nobody's neighbour)
     if constexpr (OFF_GRID) {
       bool off = false;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
         const float f = floorf(((a == 0 ? px[i] : (a == 1 ? py[i] : pz[i])) - c.gmin[a]) * c.inv_cell);
         off |= f < 0.0f || f >= (float)c.dims[a];
       }
-      if (off) *off_grid = 1;  // (benign race: every writer stores 1)
+      if (off) *off_grid = build_seq;  // (benign race: every writer stores the same number)
     }
   }
   const int prev = __shfl_up(cell, 1, kWave), prev_id = __shfl_up(id, 1, kWave);

@@ -643,15 +643,16 @@ template <bool GHOSTS, bool ADD_G, bool FAST, bool ROWS = false>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd, CSoa3 p, Soa3 pp, Soa3 pv, CSoa3 gterm,
                                                             Soa3 frc, int* __restrict__ qcount, int* __restrict__ qrank,
                                                             int* __restrict__ n_qtiles, unsigned int* __restrict__ drift,
-                                                            const int* __restrict__ off_grid, float* __restrict__ press,
-                                                            DevStats* stats, float4* __restrict__ qrows = nullptr,
+                                                            const int* __restrict__ off_grid, int build_seq,
+                                                            float* __restrict__ press, DevStats* stats,
+                                                            float4* __restrict__ qrows = nullptr,
                                                             int row_slots = 0, float4* __restrict__ spill = nullptr,
                                                             int* __restrict__ n_spill = nullptr) {
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (!ROWS && i == 0 && n_qtiles != nullptr) *n_qtiles = 0;  // the length of this iteration's query-tile list (k_qtile_list)
   const int lane = threadIdx.x & (kWave - 1);
-  const bool all_inside = *off_grid == 0;
+  const bool all_inside = *off_grid != build_seq;  // (the current build's number: k_cell_rank)
   int cell = -1;
   bool left = false, mine = false;
   unsigned int err_bits = 0u;
@@ -781,7 +782,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_density_binned(DevConsts c, Neig
 }
 
 // end of one correction iteration :95-98
-__global__ void k_pci_check(DevConsts c, DevStats* stats) {
+// (`iter_counters`: the query-tile list length and the spill count of the binned iteration -- zero for the next one)
+__global__ void k_pci_check(DevConsts c, DevStats* stats, int* __restrict__ iter_counters) {
+  if (iter_counters != nullptr) iter_counters[0] = iter_counters[1] = 0;
   if (stats->pci_done) return;
   const unsigned int e = stats->pci_cur_err_bits;
   stats->pci_last_err_bits = e;
@@ -789,7 +792,8 @@ __global__ void k_pci_check(DevConsts c, DevStats* stats) {
   stats->pci_cur_err_bits = 0u;
   if (__uint_as_float(e) <= c.pci_max_error) stats->pci_done = 1;
 }
-__global__ void k_pci_reset(DevStats* stats) {
+__global__ void k_pci_reset(DevStats* stats, int* __restrict__ iter_counters) {
+  if (iter_counters != nullptr) iter_counters[0] = iter_counters[1] = 0;
   stats->pci_done = 0;
   stats->pci_iters = 0;
   stats->pci_cur_err_bits = 0u;
