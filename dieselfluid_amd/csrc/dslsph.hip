@@ -83,6 +83,9 @@ struct dsl_handle {
   // -1 = never (dsl_pcisph_set_binning; DSL_PCI_BINNED presets it)
   int pci_bin_mode = 0;
   int build_seq = 0;  // neighbour builds so far (k_cell_rank<true> stamps its off-grid flag with it)
+  // the query histogram was handed to an iteration that may not have cleaned it again (the table builder / the scan do,
+  // behind the predictor: an error return in between leaves it dirty -- the sort's sort_scratch_dirty, for the queries)
+  bool qcount_dirty = false;
   bool pci_counters_clean = false;  // n_qtiles[0..1] are known to be zero (the first binned iteration clears them itself)
   bool pci_iter_pending = false;  // DSL_PCI_ITERATE without its DSL_PCI_CHECK yet (the check clears the iteration's counters)
   bool pci_binned = false;
@@ -1664,6 +1667,8 @@ int pci_iterate(dsl_handle* h) {
     CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
     const bool qtiled = tiled && h->pci_qtiled;
     const bool rows = qtiled && h->pci_qpair && h->pci_qrows && h->qrows != nullptr;
+    if (h->qcount_dirty) HIP_TRY(h, hipMemsetAsync(h->qcount, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+    h->qcount_dirty = true;
     // n_qtiles[0] tile list length, [1] spilled queries: left at zero by k_pci_reset / k_pci_check (a memset node costs
     // 7 us on the device, four per step); only a host that iterates twice without the check in between gets one here
     if (rows && (h->pci_iter_pending || !h->pci_counters_clean)) HIP_TRY(h, hipMemsetAsync(h->n_qtiles, 0, 2 * sizeof(int), h->stream));
@@ -1699,6 +1704,8 @@ int pci_iterate(dsl_handle* h) {
       }
     });
     if (rc) return rc;
+    HIP_TRY(h, hipGetLastError());
+    h->qcount_dirty = false;  // (the kernels that leave the histogram zeroed are queued)
     rc = timed(h, DSL_K_PCI_DENSITY, [&] {
       if (rows) {
         hipLaunchKernelGGL(k_pci_density_qpair<true>, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
