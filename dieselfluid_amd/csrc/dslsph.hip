@@ -1618,7 +1618,12 @@ int pci_begin_step(dsl_handle* h) {
   if (int rc = pci_drift_check(h)) return rc;
   if (int rc = build_grid(h, false)) return rc;
   if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
-  if (int rc = materialise_forces(h)) return rc;
+  // Forces still at their reset value (Update leaves them so, nothing materialised): the tiled set-up sweep below writes
+  // reset + its terms itself instead of adding to a filled array -- when every live slot is one of its targets (no
+  // boundary particles, no ghosts), so that no slot is left unwritten
+  const bool fill_in_sweep = h->forces_uniform && pci_tiled(h) && h->nb == 0 && !h->c.n_ptr && !h->lsh;
+  if (!fill_in_sweep)
+    if (int rc = materialise_forces(h)) return rc;
   if (int rc = materialise_press(h)) return rc;
   CSoa3 p = cpos(h), v = cvel(h);
   Soa3 F = mfrc(h);
@@ -1634,13 +1639,14 @@ int pci_begin_step(dsl_handle* h) {
       if (XS)
         hipLaunchKernelGGL((k_force_integrate_tiled<true, true, kOutPci, true>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h), G);
+                           h->pterm, cF, fill_in_sweep ? 1 : 0, F, xs, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h), G);
       else
         hipLaunchKernelGGL((k_force_integrate_tiled<true, true, kOutPci>), dim3(persistent_grid(h, 2)),
                            dim3(kTBlock), 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, nullptr, nullptr, h->tile_desc, h->cell_start, p, v, h->rho,
-                           h->pterm, cF, 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h), G);
+                           h->pterm, cF, fill_in_sweep ? 1 : 0, F, none, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, nullptr, bnd_of(h), G);
     });
     if (rc) return rc;
+    if (fill_in_sweep) h->forces_uniform = false;
   } else {
     if (int rc = viscous_pass(h, XS ? 1 : 0)) return rc;
   }

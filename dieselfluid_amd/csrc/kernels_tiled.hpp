@@ -2166,9 +2166,17 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
         if (sub != 0) return;  // the group's first lane finishes the target
       }
       if constexpr (OUT == kOutAddForce || OUT == kOutPci) {
-        pout.x[g] += fx;
-        pout.y[g] += fy;
-        pout.z[g] += fz;
+        if (OUT == kOutPci && forces_uniform) {
+          // (PCISPH step set-up with the forces still at their reset value, nowhere materialised: this IS the fill --
+          // reset + f is the one addition `+=` would have done on the filled array)
+          pout.x[g] = c.reset[0] + fx;
+          pout.y[g] = c.reset[1] + fy;
+          pout.z[g] = c.reset[2] + fz;
+        } else {
+          pout.x[g] += fx;
+          pout.y[g] += fy;
+          pout.z[g] += fz;
+        }
         if constexpr (WANT_XS) {  // XSPH correction for the later Update
           vout.x[g] = xsx;
           vout.y[g] = xsy;
