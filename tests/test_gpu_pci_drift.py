@@ -98,12 +98,18 @@ def test_fast_run_does_not_depend_on_call_grouping(mode):
     assert res[0][4] == (mode >= 0)  # by step 36 more than 0.2 % of the queries have left their tile
 
 
-def test_binned_density_matches_a_float64_brute_force_after_the_drift():
+@pytest.mark.parametrize("variant", ["", "DSL_PCI_QROWS=0", "DSL_PCI_QPAIR=0", "DSL_PCI_QTILED=0"])
+def test_binned_density_matches_a_float64_brute_force_after_the_drift(variant, monkeypatch):
     """FAST, 64^3 particles, 60 steps (median drift ~ 1/3 h, every fifth query in another tile): the pressure accumulator
     after the first correction iteration of the next step is (rho* - rho0) delta with rho* a float64 brute-force DensityF
-    at the downloaded predicted positions -- for queries INSIDE the fluid, at its surface and outside it."""
+    at the downloaded predicted positions -- for queries INSIDE the fluid, at its surface and outside it.
+    The variants are the forms the library falls back to: the sorted query array instead of per-cell rows (also what an
+    allocation failure of the rows selects), one query per lane, the global-memory sweep."""
     from dieselfluid_amd import SPHEngine
     from scipy.spatial import cKDTree
+    if variant:
+        k, v = variant.split("=")
+        monkeypatch.setenv(k, v)
     p, pos = _scene(64, FAST)
     eng = SPHEngine(p, device=0)
     eng.upload("positions", pos)
