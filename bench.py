@@ -88,13 +88,65 @@ def cpu_baseline(args):
     }
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as a CHILD
+    `torch.distributed.run` (this process has not touched the GPU and never will: it only waits for the child and
+    exits with its code -- no exec from a process that has initialised HIP).  Under a launcher (WORLD_SIZE set) the
+    world size must be the one asked for: a mismatch exits 2 instead of silently measuring another job."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or without a launcher: bench.py starts the ranks itself)\n")
+        raise SystemExit(2)
+    return world
+
+
+class Watchdog:
+    """A collective that never completes (a rank missing, a group left open) must end the run with a non-zero exit
+    code, not hang it: a timer thread ends the process -- os._exit, nothing is re-executed -- when a phase overruns.
+    The main thread may be inside a C call (ctypes releases the GIL), the timer still fires."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.timer = None
+
+    def arm(self, seconds, what):
+        import threading
+        self.disarm()
+
+        def fire():
+            sys.stderr.write(f"bench.py: rank {self.rank}: '{what}' did not finish within {seconds:.0f} s -- "
+                             "a collective is stuck; exiting 4\n")
+            sys.stderr.flush()
+            os._exit(4)
+
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     args = parse()
+    world = launch_ranks(args)  # (before anything touches the GPU)
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("DSL_BENCH_BACKEND", "nccl")
@@ -103,14 +155,22 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
+    dog = Watchdog(rank)
+    limit = float(os.environ.get("DSL_BENCH_WATCHDOG_S", "300"))
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.arm(limit, "process group set-up")
         # RCCL over xGMI; DSL_BENCH_BACKEND=gloo only exists to rehearse this code path with
         # several ranks on a one-GPU box (every rank then uses cuda:DSL_BENCH_DEVICE)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=limit))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=limit))
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus asked for {args.gpus}\n")
+            os._exit(2)
 
     from dieselfluid_amd import SPHEngine, scenes
 
@@ -174,15 +234,21 @@ def main():
     # kernels (the roofline's) inside the timed region and the rest in a short segment after it;
     # N>1 times everything in that segment, `value` is measured without any.
     events_in_region = world == 1
+    if world > 1:
+        dog.arm(limit, "warm-up steps (first halo exchange)")
     step(args.warmup)
     for e in engines:
         e.timing_reset()
         e.timing_enable(2 if events_in_region else 0)
     barrier()
+    if world > 1:
+        dog.arm(limit, "timed steps")
     t0 = time.perf_counter()
     step(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        dog.arm(limit, "per-kernel timing segment and the closing reductions")
     hot = {k: engines[0].timing(k) for k in ("density", "force_integrate", "pci_density")}
     timed_launch_steps = min(args.steps, 10)
     for e in engines:
@@ -199,6 +265,15 @@ def main():
 
     eng = engines[0]
     overflow = band_missed = query_escaped = 0
+    # how many ranks the communicator the halo exchange runs on REALLY spans (ncclCommCount inside the library;
+    # the python protocol: the process group's own size) -- must be --gpus
+    ranks_seen = 1
+    if world > 1:
+        nc = getattr(drv, "native_comm", None)
+        ranks_seen = nc.count() if nc is not None else dist.get_world_size()
+        if ranks_seen != args.gpus:
+            sys.stderr.write(f"bench.py: the halo communicator spans {ranks_seen} ranks, --gpus asked for {args.gpus}\n")
+            os._exit(2)
     if world > 1:
         # a band / capacity overflow or an outrun split margin would silently lose ghosts: make it visible
         # (third word: a PCISPH query point has drifted out of its rank's ghost coverage -- include/dslsph.h)
@@ -372,6 +447,7 @@ def main():
             "drifted": drifted,
             "exact": exact,
             "n_live_rank0": n_live,
+            "n_ranks_seen_by_rccl": ranks_seen,
             "slab_driver": (("native (dsl_slab_wcsph_step: RCCL inside libdslsph.so)" if backend == "nccl" else
                              "native (dsl_slab_wcsph_step over a host-staged dsl_comm_create_custom transport)")
                             if world > 1 and getattr(drv, "native", False)
@@ -380,6 +456,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
+    dog.disarm()
     if world > 1:
         dist.destroy_process_group()
 

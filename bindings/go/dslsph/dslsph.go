@@ -202,6 +202,15 @@ func NewComm(nranks, rank int, id [128]byte, device int) (*Comm, error) {
 }
 func (c *Comm) Close() { C.dsl_comm_destroy(c.c); c.c = nil }
 
+// Count: the ranks the communicator really spans (ncclCommCount).
+func (c *Comm) Count() (int, error) {
+	var n C.int
+	if rc := C.dsl_comm_count(c.c, &n); rc != 0 {
+		return 0, errors.New(C.GoString(C.dsl_comm_last_error()))
+	}
+	return int(n), nil
+}
+
 // NewCommCustom: a communicator over the host's own transport (MPI, sockets, ...) instead of RCCL.  The table's
 // callbacks are C function pointers (exported Go functions via //export, or plain C); the library calls them in
 // exactly the order it would call RCCL (dsl_transport in include/dslsph.h).

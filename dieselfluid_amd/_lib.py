@@ -130,6 +130,7 @@ EXPORTS = {
     "dsl_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_vp)]),
     "dsl_comm_create_custom": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "dsl_comm_destroy": (C.c_int, [_vp]),
+    "dsl_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dsl_comm_last_error": (C.c_char_p, []),
     "dsl_create_multi": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(_vp)]),
     "dsl_slab_attach": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),

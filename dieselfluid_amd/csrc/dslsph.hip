@@ -856,6 +856,7 @@ int alloc_query_bins(dsl_handle* h) {
         h->qrows = nullptr;
         h->pci_qrows = false;
         h->err.clear();
+        (void)hipGetLastError();  // (since ROCm 7.0 the last NON-SUCCESS error sticks: the next launch check would report this one)
       }
     }
   }
@@ -2191,6 +2192,24 @@ int dsl_comm_destroy(dsl_comm* c) {
   return DSL_OK;
 }
 
+int dsl_comm_count(dsl_comm* c, int* nranks) {
+  if (!c || !nranks) {
+    g_comm_error = "dsl_comm_count: bad argument";
+    return DSL_ERR_INVALID;
+  }
+  *nranks = c->nranks;
+  if (!c->custom && c->comm) {
+    int n = 0;
+    const ncclResult_t r = rccl().CommCount(c->comm, &n);
+    if (r != ncclSuccess) {
+      g_comm_error = std::string("ncclCommCount: ") + rccl().GetErrorString(r);
+      return DSL_ERR_DEVICE;
+    }
+    *nranks = n;
+  }
+  return DSL_OK;
+}
+
 int dsl_create_multi(const dsl_params* params, int ndev, const int* devices, dsl_handle** handles, dsl_comm** comms) {
   if (!params || !devices || !handles || !comms || ndev < 1) return fail(nullptr, DSL_ERR_INVALID, "dsl_create_multi: bad argument");
   for (int k = 0; k < ndev; ++k) handles[k] = nullptr, comms[k] = nullptr;
@@ -2292,21 +2311,33 @@ int link_post(dsl_handle* h, hipStream_t st) {
   const size_t n = dsl_slab_message_floats_for(h, L.cap_full, L.cap_x);
   dsl_comm* comm = L.comm;
   if (int rc = xfer_group_start(h, comm)) return rc;
-  if (L.lo >= 0)
-    if (int rc = xfer_send(h, comm, L.send[0], n, L.lo, st)) return rc;
-  if (L.hi >= 0)
-    if (int rc = xfer_send(h, comm, L.send[1], n, L.hi, st)) return rc;
-  // two messages between the same pair of ranks (two ranks with periodic images, or a rank that is
-  // its own neighbour in a test) are matched in issue order: the peer's LOW band arrives from above
-  const bool same_peer = L.lo >= 0 && L.lo == L.hi;
-  if (same_peer) {
-    if (int rc = xfer_recv(h, comm, L.recv[1], n, L.hi, st)) return rc;
-    if (int rc = xfer_recv(h, comm, L.recv[0], n, L.lo, st)) return rc;
-  } else {
+  // (an error between group start and group end must not leave the group open: every later RCCL call of the
+  // process would be queued into it and nothing would ever be sent -- close it, keep the first error)
+  auto body = [&]() -> int {
     if (L.lo >= 0)
-      if (int rc = xfer_recv(h, comm, L.recv[0], n, L.lo, st)) return rc;
+      if (int rc = xfer_send(h, comm, L.send[0], n, L.lo, st)) return rc;
     if (L.hi >= 0)
+      if (int rc = xfer_send(h, comm, L.send[1], n, L.hi, st)) return rc;
+    // two messages between the same pair of ranks (two ranks with periodic images, or a rank that is
+    // its own neighbour in a test) are matched in issue order: the peer's LOW band arrives from above
+    const bool same_peer = L.lo >= 0 && L.lo == L.hi;
+    if (same_peer) {
       if (int rc = xfer_recv(h, comm, L.recv[1], n, L.hi, st)) return rc;
+      if (int rc = xfer_recv(h, comm, L.recv[0], n, L.lo, st)) return rc;
+    } else {
+      if (L.lo >= 0)
+        if (int rc = xfer_recv(h, comm, L.recv[0], n, L.lo, st)) return rc;
+      if (L.hi >= 0)
+        if (int rc = xfer_recv(h, comm, L.recv[1], n, L.hi, st)) return rc;
+    }
+    return DSL_OK;
+  };
+  const int rc = body();
+  if (rc != DSL_OK) {
+    const std::string first = h->err;
+    (void)xfer_group_end(h, comm);
+    h->err = first;
+    return rc;
   }
   return xfer_group_end(h, comm);
 }

@@ -53,7 +53,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
                                                       unsigned int* __restrict__ unordered, DevStats* stats,
                                                       int* __restrict__ n_tiles, int* __restrict__ cell_keys,
                                                       int* __restrict__ overfull, int* __restrict__ off_grid,
-                                                      int build_seq) {
+                                                      int build_seq, SkinGate gate = SkinGate{nullptr},
+                                                      const int* __restrict__ ids_alt = nullptr) {
+  if (gate.closed()) return;
+  // (skin step: `ids` is map 0, `ids_alt` map 1; the device state names the map that is current AFTER this rebuild,
+  // so the one to read -- the order before the sort -- is the other)
+  if (gate.st != nullptr && ids != nullptr && gate.st->ids_sel == 0) ids = ids_alt;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   // the small counters of the later kernels of this build (the fullest-cell statistic of the scan, the tile-list
   // lengths): cleared here, at the head of the build, when the one-launch scan is in use (stats != nullptr)
@@ -141,8 +146,10 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* lds, int& total)
 // (block 0 also clears the small counters of the later kernels -- the fullest-cell statistic of phase 3, the tile-list
 // lengths -- which used to be the job of a one-block middle phase; phase 3 now adds up its predecessors' sums itself)
 __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ count, int* __restrict__ block_sums,
-                                                       DevStats* stats, int* __restrict__ n_tiles) {
+                                                       DevStats* stats, int* __restrict__ n_tiles,
+                                                       SkinGate gate = SkinGate{nullptr}) {
   __shared__ int lds[kBlock / kWave];
+  if (gate.closed()) return;
   if (blockIdx.x == 0 && stats != nullptr) {  // (stats == nullptr: a scan that is not the particles' build -- PCISPH query bins)
     if (threadIdx.x == 0) stats->max_cell_count = 0;
     if (n_tiles && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
@@ -163,8 +170,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ co
 // (the histogram is left zeroed for the next build: saves that build a memset launch)
 __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
                                                        const int* __restrict__ block_sums,
-                                                       int* __restrict__ cell_start, DevStats* stats) {
+                                                       int* __restrict__ cell_start, DevStats* stats,
+                                                       SkinGate gate = SkinGate{nullptr}) {
   __shared__ int lds[kBlock / kWave];
+  if (gate.closed()) return;
   int4* src = reinterpret_cast<int4*>(count + (size_t)blockIdx.x * kScanTile);
   int4* dst = reinterpret_cast<int4*>(cell_start + (size_t)blockIdx.x * kScanTile);
   // the tile's offset: the sum of the tile sums in front of it (at most a few thousand ints, L2-resident: cheaper than
@@ -356,9 +365,20 @@ __device__ __forceinline__ void scatter_move(const ScatterArrays& a, const Scatt
 }
 
 // `pos`: the unsorted positions the ranks were computed from
+// (skin step: the host passes map 0 as a.ids_src and map 1 as a.ids_dst; the device state names the map that is current
+// AFTER this rebuild -- the sort's destination)
+__device__ __forceinline__ void skin_ids(ScatterArrays& a, const SkinGate& gate) {
+  if (gate.st != nullptr && gate.st->ids_sel == 0) {  // the new current map is 0: scatter 1 -> 0
+    const int* s = a.ids_dst;
+    a.ids_dst = const_cast<int*>(a.ids_src);
+    a.ids_src = s;
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                     const int* __restrict__ rank,
-                                                    const int* __restrict__ cell_start) {
+                                                    const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr}) {
+  if (gate.closed()) return;
+  skin_ids(a, gate);
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c)) return;
   bool later = false;
@@ -392,7 +412,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
 
 __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                             const int* __restrict__ rank,
-                                                            const int* __restrict__ cell_start) {
+                                                            const int* __restrict__ cell_start,
+                                                            SkinGate gate = SkinGate{nullptr}) {
+  if (gate.closed()) return;
+  skin_ids(a, gate);
   if (o.cell_keys != nullptr) {
     // fallback of the one-pass ordering: only the marked cells with more than kCellKeys members are left, and only
     // if k_cell_rank has seen such a cell at all.  A small grid strides over the particles.

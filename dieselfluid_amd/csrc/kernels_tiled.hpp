@@ -126,7 +126,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
                                                       int* __restrict__ tiles, int* __restrict__ n_tiles,
                                                       int* __restrict__ short_pass_tiles, int* __restrict__ n_live,
                                                       int* __restrict__ desc_of, unsigned int* __restrict__ unordered,
-                                                      int unordered_words, int* __restrict__ overfull) {
+                                                      int unordered_words, int* __restrict__ overfull,
+                                                      SkinGate gate = SkinGate{nullptr}) {
+  if (gate.closed()) return;
   const int lt = blockIdx.x * kBlock + threadIdx.x;  // list thread: tiles are enumerated box by box (TileGrid)
   if (lt == 0) *overfull = 0;  // k_cell_rank's "a cell outgrew its key row" flag has been consumed by the scatter
   // the sort's "cells to order" bitmap (kernels_grid.hpp) has been consumed: clean for the next build
@@ -277,8 +279,11 @@ __device__ __forceinline__ void tile_setup_load_counts(const DevConsts& c, const
 __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, const int* __restrict__ cell_start,
                                                      const int* __restrict__ target_start,
                                                      const int* __restrict__ tiles, const int* __restrict__ n_tiles,
-                                                     int* __restrict__ desc, int* __restrict__ query_counts = nullptr) {
+                                                     int* __restrict__ desc, int* __restrict__ query_counts = nullptr,
+                                                     int lds_cap = kTCap, SkinGate gate = SkinGate{nullptr}) {
   // (query_counts != nullptr: query rows, see tile_setup_load_counts; target_start is then unused)
+  // (lds_cap: staged records the sweeping kernel's LDS image holds -- kTCap, or the skin step's wider image)
+  if (gate.closed()) return;
   const int n = *n_tiles;
   const int lane = threadIdx.x;
   const int ry = lane % kTH, rz = lane / kTH;
@@ -325,13 +330,13 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
         // (a tile that overflows the LDS budget is never staged: its packed run bounds may be garbage.  Target
         // indices fit 16 bits as long as the staged records do -- the targets are among them; QUERY targets are not,
         // and a tile with more of them than 16 bits count takes the global-memory sweep as well)
-        out->overflow = (inc > kTCap || tinc > 0xffff) ? 1 : 0;
+        out->overflow = (inc > lds_cap || tinc > 0xffff) ? 1 : 0;
         out->tprefix[kTB * kTB] = tinc;
         out->pprefix[kTB * kTB] = pinc;
         out->tile = tile;
-        out->centre[0] = __float_as_int(c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.h);
-        out->centre[1] = __float_as_int(c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.h);
-        out->centre[2] = __float_as_int(c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.h);
+        out->centre[0] = __float_as_int(c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.cell);
+        out->centre[1] = __float_as_int(c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.cell);
+        out->centre[2] = __float_as_int(c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.cell);
       }
     }
   };
@@ -1195,15 +1200,22 @@ __device__ __forceinline__ PairSlot pair_slot(const TileMeta& m, int u) {
   return r;
 }
 
-template <bool SHARE>
-__global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+// WIDE (the skin step's candidate sweep, kernels_skin.hpp): the grid's cells are h (1 + s) wide, the masks take every
+// candidate within that distance (`wide_thr` = 1 - (1 + s)^2, less a rounding margin: the test is 1 - r^2/h^2 > wide_thr),
+// densities are not formed here (k_density_list forms them, every step, from the lists these masks become), and the
+// LDS image is the wider kTCapWide records.
+constexpr int kTCapWide = 3072;  // 6 cells x 1.1 x 2 particles per h = 13.2 lattice planes per axis: up to 14^3 = 2744
+template <bool SHARE, bool WIDE = false>
+__global__ __launch_bounds__(kPBlock, WIDE ? 3 : 4) void k_density_pair(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                              const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                              const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
                                                              float* __restrict__ rho, float* __restrict__ pterm,
-                                                             unsigned int* __restrict__ nmask, int mstride) {
+                                                             unsigned int* __restrict__ nmask, int mstride,
+                                                             float wide_thr = 0.0f, SkinGate gate = SkinGate{nullptr}) {
   __shared__ TileMeta metas[2];
-  __shared__ float4 A[kTCap];
+  __shared__ float4 A[WIDE ? kTCapWide : kTCap];
   const int tid = threadIdx.x;
+  if (gate.closed()) return;
   if (c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
   auto load4 = [&](int g, float4* o) {
     o[0] = load4u(p.x + g);
@@ -1292,6 +1304,13 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
               const float4 cnd = A[jj + v];
+              if constexpr (WIDE) {  // 1 - r^2/h^2 unclamped against the skin's threshold; nothing is summed
+                const float t0 = __builtin_fmaf(cnd.z, sz0, __builtin_fmaf(cnd.y, sy0, __builtin_fmaf(cnd.x, sx0, cnd.w + a00)));
+                const float t1 = __builtin_fmaf(cnd.z, sz1, __builtin_fmaf(cnd.y, sy1, __builtin_fmaf(cnd.x, sx1, cnd.w + a01)));
+                mask_push_lt(mask0, wide_thr, t0);
+                mask_push_lt(mask1, wide_thr, t1);
+                continue;
+              }
               const float q0 = fma_clamp01(cnd.z, sz0, __builtin_fmaf(cnd.y, sy0, __builtin_fmaf(cnd.x, sx0, cnd.w + a00)));
               const float q1 = fma_clamp01(cnd.z, sz1, __builtin_fmaf(cnd.y, sy1, __builtin_fmaf(cnd.x, sx1, cnd.w + a01)));
               mask_push(mask0, q0);
@@ -1339,7 +1358,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
         }
         acc[0] += accb[0];
         acc[1] += accb[1];
-      } else if (sub == 0) {
+      } else if (!WIDE && sub == 0) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           if (e == 1 && !two) break;
@@ -1358,6 +1377,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
           acc[e] = a;
         }
       }
+      if constexpr (WIDE) return;  // (masks only: a tile that overflows the image has none, k_list_build marks its targets)
       if constexpr (SHARED) {
         for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
           acc[0] += __shfl_xor(acc[0], o, kWave);

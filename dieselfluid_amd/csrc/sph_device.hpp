@@ -37,6 +37,7 @@ struct DevConsts {
   // uniform grid: cell edge = h, x-fastest linearisation
   float gmin[3];
   float inv_cell;
+  float cell;  // cell edge: h, or h (1 + skin) while the skin step owns the grid (kernels_skin.hpp)
   int dims[3];
   int ncell;
   // slab ownership (multi-GPU): axis < 0 = everything owned
@@ -89,6 +90,28 @@ struct DevStats {
   // lies more than h beyond a slab plane, i.e. outside what the 2h ghost band covers: its sum is missing neighbours
   // that live on another rank, and the run no longer equals the single-domain run (dsl_slab_status[1], bit 1)
   int pci_escaped;
+};
+
+// The skin step's device-resident state (kernels_skin.hpp; DSL_OPT_SKIN): neighbour LISTS are built against the cut-off
+// h (1 + s) and walked for as many steps as no particle can have moved further than s h / 2 since they were built.  That
+// decision is the device's -- k_skin_decide, first kernel of every step -- so that the host never waits for it: every
+// kernel of the rebuild chain takes a gate and returns at once while `rebuild` is 0.
+struct SkinState {
+  int rebuild;      // this step rebuilds: counting sort, candidate sweep, lists
+  int ids_sel;      // which of the two slot -> particle maps is current (a rebuild flips it on the device)
+  float disp;       // upper bound of any particle's displacement since the lists were built
+  unsigned int step_vmax_bits;  // max |v|^2 of the step just integrated (bits of a non-negative float)
+  int force;        // host request: rebuild at the next step whatever the bound says
+  int n_steps, n_rebuilds;
+  int list_overflow;  // targets whose list did not fit (they take the global-memory sweep)
+  float budget;     // s h / 2, less a rounding margin
+  float dt;
+  int pad_[6];
+};
+// the gate every kernel of the rebuild chain takes (st == nullptr: no gate, the kernel always runs)
+struct SkinGate {
+  const SkinState* st;
+  __device__ __forceinline__ bool closed() const { return st != nullptr && st->rebuild == 0; }
 };
 
 // ---------------------------------------------------------------------------------

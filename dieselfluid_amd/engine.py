@@ -60,6 +60,14 @@ class Comm:
         if rc:
             raise DslError(f"dsl_comm_create failed ({rc}): {self._L.dsl_comm_last_error().decode()}")
 
+    def count(self) -> int:
+        """ranks the communicator really spans (ncclCommCount)"""
+        n = C.c_int(0)
+        rc = self._L.dsl_comm_count(self.ptr, C.byref(n))
+        if rc:
+            raise DslError(f"dsl_comm_count failed ({rc}): {self._L.dsl_comm_last_error().decode()}")
+        return int(n.value)
+
     def close(self):
         if getattr(self, "ptr", None):
             self._L.dsl_comm_destroy(self.ptr)

@@ -258,6 +258,7 @@ class SlabDriver:
         core.slab_attach(comm, -1 if lo_nb is None else lo_nb, -1 if hi_nb is None else hi_nb, self.width_full,
                          self.width, self.engine.cap_full, self.engine.cap_x, self.overlap)
         self.native = True
+        self.native_comm = comm
         return comm
 
     def wcsph_step(self, nsteps: int = 1):

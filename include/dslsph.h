@@ -393,6 +393,9 @@ int dsl_comm_unique_id(uint8_t id[DSL_COMM_ID_BYTES]);
 int dsl_comm_create(int nranks, int rank, const uint8_t id[DSL_COMM_ID_BYTES], int device, dsl_comm **out);
 int dsl_comm_create_all(int ndev, const int *devices, dsl_comm **out /* ndev */);
 int dsl_comm_destroy(dsl_comm *c);
+/* ncclCommCount: how many ranks the communicator REALLY spans (a custom transport: the count it was created
+ * with).  A bench or a host that asked for N ranks checks this instead of trusting its own arithmetic. */
+int dsl_comm_count(dsl_comm *c, int *nranks);
 const char *dsl_comm_last_error(void);
 /* A communicator over the HOST'S OWN transport instead of RCCL (MPI, a socket layer, a test shim): the slab
  * drivers make exactly the same sequence of calls through this table as they make to RCCL (one group per
