@@ -33,8 +33,8 @@ BYTES_FORCE = 52
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n3", type=int, default=252, help="fluid block edge in particles (252 -> 16.0M)")
     ap.add_argument("--math", choices=["fast", "exact"], default="fast")
     ap.add_argument("--method", choices=["wcsph", "pcisph"], default="wcsph",
@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--pci-iters", type=int, default=4)
     ap.add_argument("--extra-terms", action="store_true",
                     help="BASELINE configs[4]: add the build-defined XSPH + cohesion (surface tension) terms")
+    ap.add_argument("--skin", type=float, default=None,
+                    help="N=1 WCSPH, --math fast: DSL_OPT_SKIN, neighbour lists against h (1 + skin) that live until some "
+                         "particle has moved skin h / 2 (0 = sort and sweep every step; default: the library's own default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the whole force pass")
     ap.add_argument("--developed-steps", type=int, default=10000,
@@ -192,6 +195,8 @@ def main():
         eng = SPHEngine(p, device=local_rank)
         eng.upload("positions", pos)
         eng.reset_forces()
+        if args.skin is not None:
+            eng.set_option("skin", args.skin)
         del pos
         if args.method == "pcisph":
             eng.pcisph_begin()
@@ -243,10 +248,12 @@ def main():
     barrier()
     if world > 1:
         dog.arm(limit, "timed steps")
+    skin0 = (engines[0].get_option("skin_steps"), engines[0].get_option("skin_rebuilds")) if world == 1 else (0, 0)
     t0 = time.perf_counter()
     step(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    skin1 = (engines[0].get_option("skin_steps"), engines[0].get_option("skin_rebuilds")) if world == 1 else (0, 0)
     if world > 1:
         dog.arm(limit, "per-kernel timing segment and the closing reductions")
     hot = {k: engines[0].timing(k) for k in ("density", "force_integrate", "pci_density")}
@@ -306,10 +313,12 @@ def main():
         kname, kms, kbytes = "k_force_integrate", ms_f, BYTES_FORCE
     else:
         kname, kms, kbytes = "k_density", ms_d, BYTES_DENSITY
+    if world == 1 and args.method == "wcsph" and skin1[0] > skin0[0]:  # the timed steps walked neighbour lists
+        kname = {"k_force_integrate": "k_force_list", "k_density": "k_density_list"}[kname]
     achieved = n_local * kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     st = eng.stats()
     kernels_ms = {k: round(timing_of(k)[0], 4) for k in
-                  (("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")
+                  (("cell_rank", "scan", "scatter", "tile_list", "neigh_lists", "density", "force_integrate")
                    if args.method == "wcsph" else
                    ("cell_rank", "scan", "scatter", "tile_list", "density", "viscous", "gradient",
                     "pci_predict", "pci_density", "update"))}
@@ -354,7 +363,7 @@ def main():
         eng.timing_reset()
         eng.timing_enable(True)
         step(5)
-        dk = {k: round(eng.timing(k)[0], 4) for k in ("cell_rank", "scan", "scatter", "tile_list", "density", "force_integrate")}
+        dk = {k: round(eng.timing(k)[0], 4) for k in ("cell_rank", "scan", "scatter", "tile_list", "neigh_lists", "density", "force_integrate")}
         eng.timing_enable(False)
         sd = eng.stats()
         developed = {"ms_per_step": round(td * 1e3, 4), "value": round(n_total / td / 1e6, 3), "kernels_ms": dk,
@@ -446,6 +455,12 @@ def main():
             "developed": developed,
             "drifted": drifted,
             "exact": exact,
+            # DSL_OPT_SKIN: steps of the timed region that walked neighbour lists, and how many of them rebuilt the lists
+            # (sort + candidate sweep) -- the region holds the share of rebuilds this phase of the flow asks for
+            "skin": {"s": eng.get_option("skin"), "steps_in_timed_region": int(skin1[0] - skin0[0]),
+                     "rebuilds_in_timed_region": int(skin1[1] - skin0[1]),
+                     "list_overflow": int(eng.get_option("skin_list_overflow")),
+                     "suspensions": int(eng.get_option("skin_suspensions"))} if world == 1 else None,
             "n_live_rank0": n_live,
             "n_ranks_seen_by_rccl": ranks_seen,
             "slab_driver": (("native (dsl_slab_wcsph_step: RCCL inside libdslsph.so)" if backend == "nccl" else

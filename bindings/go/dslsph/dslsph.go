@@ -476,6 +476,16 @@ func (e *Engine) GetParams() (C.dsl_params, error) {
 	err := e.ck(C.dsl_get_params(e.h, &p))
 	return p, err
 }
+// SetOption / GetOption: library options (DSL_OPT_* in include/dslsph.h), e.g. the neighbour-list skin of WCSPHStep.
+func (e *Engine) SetOption(option int, value float64) error {
+	return e.ck(C.dsl_set_option(e.h, C.int(option), C.double(value)))
+}
+func (e *Engine) GetOption(option int) (float64, error) {
+	var v C.double
+	err := e.ck(C.dsl_get_option(e.h, C.int(option), &v))
+	return float64(v), err
+}
+
 func (e *Engine) ResetForces() error { return e.ck(C.dsl_reset_forces(e.h)) } // the state Update leaves (fluid.go:193)
 func (e *Engine) ForcePass() error   { return e.ck(C.dsl_force_pass(e.h)) }   // fused [G] [V] X U of the WCSPH step
 

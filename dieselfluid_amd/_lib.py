@@ -140,6 +140,8 @@ EXPORTS = {
     "dsl_slab_replan": (C.c_int, [_vp]),
     "dsl_slab_wcsph_step": (C.c_int, [_vp, C.c_int]),
     "dsl_slab_pcisph_step": (C.c_int, [_vp, C.c_int]),
+    "dsl_set_option": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "dsl_get_option": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     "dsl_set_ids": (C.c_int, [_vp, _ip, C.c_size_t]),
     "dsl_reset_forces": (C.c_int, [_vp]),
     "dsl_last_error": (C.c_char_p, [_vp]),

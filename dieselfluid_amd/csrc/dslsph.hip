@@ -30,6 +30,7 @@
 
 #include "kernels_lsh.hpp"
 #include "kernels_tiled.hpp"
+#include "kernels_skin.hpp"
 
 struct SlabLink;
 
@@ -38,6 +39,9 @@ using namespace dsl;
 namespace {
 std::string g_create_error;
 }
+
+constexpr float kSkinDefault = 0.1f;             // DSL_OPT_SKIN of a DSL_MATH_FAST handle ...
+constexpr int kSkinDefaultParticles = 2000000;  // ... of at least this many particles
 
 struct dsl_handle {
   int device = 0;
@@ -122,16 +126,28 @@ struct dsl_handle {
   bool dens_held = false;
   // the histogram / "cells to order" bitmap were handed to a build that may not have cleaned them again
   bool sort_scratch_dirty = false;
-  // exclusive prefix of the cell counts in one launch (k_scan_onepass) instead of three: DSL_SCAN_ONEPASS=1.  OFF by
-  // default: measured on MI355X it is 6 x SLOWER at 16.4M cells (0.46 against 0.077 ms), 3 x at 4M, 1.3 x at 1M --
-  // all 4004 tiles are resident at once, so the look-back is one long chain of agent-scope round trips through
-  // the eight XCDs' separate L2s (profiles/README.md, r03)
-  bool scan_onepass = false;
+  // (a one-launch decoupled look-back scan was measured in round 3: 6 x SLOWER at 16.4M cells, 0.46 against 0.077 ms --
+  // all 4004 tiles are resident at once, so the look-back is one long chain of agent-scope round trips through the
+  // eight XCDs' separate L2s; profiles/README.md, r03.  Removed in round 4.)
   bool density_pair = true;  // FAST density with two targets per lane (DSL_DENSITY_PAIR=0: the lane-per-target kernel)
   int max_persistent_blocks = 0;  // DSL_PERSISTENT_BLOCKS (tests)
-  unsigned long long* scan_status = nullptr;  // one word per 4096-cell tile
-  unsigned long long* scan_ticket = nullptr;  // the ever-growing ticket counter
   int64_t steps = 0;
+  // the skin step (kernels_skin.hpp; DSL_OPT_SKIN): neighbour lists against h (1 + skin), walked until some particle may
+  // have moved skin * h / 2.  skin_live: the device's SkinState is the authority on which slot -> particle map is current
+  // and the grid's cells are h (1 + skin) wide -- every other entry point settles that first (skin_settle).
+  float skin = 0.0f;
+  bool skin_live = false;
+  int64_t skin_steps_total = 0, skin_rebuilds_total = 0;  // of the skin episodes already settled
+  bool skin_list_overflow = false;
+  // the flow outran the skin (SkinState::give_up, looked at every kSkinLook steps): plain steps until step skin_retry_at
+  int64_t skin_retry_at = 0, skin_live_steps = 0;
+  int skin_suspensions = 0;
+  int tile_box[3] = {8, 4, 4};
+  int alloc_ntiles = 0;  // tiles the tile lists and tables were allocated for
+  int tile_tbz = kTB;  // cell layers per tile along z (kernels_tiled.hpp: TileGrid::tbz); 3 while the skin step owns the grid
+  SkinState* skin_state = nullptr;
+  uint4* lists = nullptr;
+  float* pvz[6] = {};  // the sort's output set of a skin step (Z)
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
@@ -157,11 +173,20 @@ int fail(dsl_handle* h, int code, const std::string& msg) {
       return fail((h), DSL_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));          \
   } while (0)
 
-#define CHECK_HANDLE(h)                                   \
+#define CHECK_HANDLE_ONLY(h)                              \
   do {                                                    \
     if (!(h)) return fail(nullptr, DSL_ERR_INVALID, "null handle"); \
     hipError_t e__ = hipSetDevice((h)->device);           \
     if (e__ != hipSuccess) return fail((h), DSL_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e__)); \
+  } while (0)
+int skin_settle(dsl_handle* h);
+// every entry point but the step driver itself first brings a handle that is in the middle of skin steps back to the
+// plain state (one small device read: kernels_skin.hpp)
+#define CHECK_HANDLE(h)                                   \
+  do {                                                    \
+    CHECK_HANDLE_ONLY(h);                                 \
+    if ((h)->skin_live)                                   \
+      if (int rc__ = skin_settle(h)) return rc__;         \
   } while (0)
 
 inline int grid_for(int n) { return (n + kBlock - 1) / kBlock; }
@@ -227,6 +252,7 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
   c.walls = p.walls;
   c.rest = p.restitution;
   c.inv_cell = 1.0f / hh;
+  c.cell = hh;
   long long ncell = 1;
   for (int a = 0; a < 3; ++a) {
     int d = (int)ceilf((p.grid_max[a] - p.grid_min[a]) * c.inv_cell);
@@ -254,6 +280,50 @@ int make_consts(dsl_handle* h, const dsl_params& p, DevConsts& c) {
 }
 
 inline int launch_n(const dsl_handle* h) { return h->c.n_ptr ? h->cap : h->n; }
+
+// the tile grid over the current cell grid (kernels_tiled.hpp: TileGrid)
+int set_tile_grid(dsl_handle* h) {
+  TileGrid& tg = h->tg;
+  tg.tnx = (h->c.dims[0] + kTB - 1) / kTB;
+  tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
+  tg.tbz = h->tile_tbz;
+  tg.tnz = (h->c.dims[2] + tg.tbz - 1) / tg.tbz;
+  tg.ntiles = tg.tnx * tg.tny * tg.tnz;
+  const int bx = h->tile_box[0], by = h->tile_box[1], bz = h->tile_box[2];
+  tg.bx = bx;
+  tg.by = by;
+  tg.bz = bz;
+  tg.nbx = bx ? (tg.tnx + bx - 1) / bx : 0;
+  tg.nby = bx ? (tg.tny + by - 1) / by : 0;
+  const long long nlist = bx ? (long long)tg.nbx * tg.nby * ((tg.tnz + bz - 1) / bz) * (bx * by * bz) : tg.ntiles;
+  if (nlist > 0x7fffffffLL) return fail(h, DSL_ERR_INVALID, "tile grid too large");
+  tg.nlist = (int)nlist;
+  return DSL_OK;
+}
+
+// Cells `edge` wide over the same grid box: the skin step widens them to h (1 + skin) and back.  Every array was sized
+// for the finest grid (edge = h, at creation), a coarser one fits in; the histogram and the "cells to order" bitmap are
+// left clean by every complete build whatever the grid.
+int set_cell_edge(dsl_handle* h, float edge, int tbz = kTB) {
+  DevConsts& c = h->c;
+  h->tile_tbz = tbz;
+  c.cell = edge;
+  c.inv_cell = 1.0f / edge;
+  long long ncell = 1;
+  for (int a = 0; a < 3; ++a) {
+    int d = (int)ceilf((h->prm.grid_max[a] - h->prm.grid_min[a]) * c.inv_cell);
+    if (d < 1) d = 1;
+    c.dims[a] = d;
+    ncell *= d;
+  }
+  c.ncell = (int)ncell;
+  h->ncell = c.ncell;
+  h->ncell_pad = ((h->ncell + 1 + kScanTile - 1) / kScanTile) * kScanTile;
+  h->nscan = h->ncell_pad / kScanTile;
+  h->grid_valid = false;
+  h->masks_valid = false;
+  return set_tile_grid(h);
+}
 
 template <class T>
 int dev_alloc(dsl_handle* h, T** p, size_t count) {
@@ -383,7 +453,6 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     if (h->unordered) HIP_TRY(h, hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream));
   }
   h->sort_scratch_dirty = true;
-  const bool onepass = h->scan_onepass;
   // PCISPH: "a particle lies outside the grid's bounds" (dcounter[4] = the number of the last build that saw one;
   // k_pci_predict_bin finishes far-away queries on the spot when this build saw none)
   h->build_seq = h->build_seq == INT_MAX ? 1 : h->build_seq + 1;  // (never 0: the flag word starts zeroed)
@@ -391,21 +460,14 @@ int build_grid(dsl_handle* h, bool carry_derived) {
     if (h->pci_active)
       hipLaunchKernelGGL(k_cell_rank<true>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                          ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
-                         onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
-                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->dcounter + 4, h->build_seq);
+                         nullptr, nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->dcounter + 4, h->build_seq);
     else
       hipLaunchKernelGGL(k_cell_rank<false>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                          ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
-                         onepass ? h->dstats : nullptr, (onepass && !h->lsh) ? h->n_tiles : nullptr,
-                         ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0);
+                         nullptr, nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
-    if (onepass) {  // one launch, the counts read once (kernels_grid.hpp: k_scan_onepass)
-      hipLaunchKernelGGL(k_scan_onepass, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->cell_start,
-                         h->scan_status, h->scan_ticket, h->nscan, h->dstats);
-      return;
-    }
     hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums, h->dstats,
                        !h->lsh ? h->n_tiles : nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
@@ -791,8 +853,9 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->pci_drift);
   if (h->pci_drift_host) (void)hipHostFree(h->pci_drift_host);
   if (h->ev_drift) (void)hipEventDestroy(h->ev_drift);
-  (void)hipFree(h->scan_status);
-  (void)hipFree(h->scan_ticket);
+  (void)hipFree(h->skin_state);
+  (void)hipFree(h->lists);
+  for (int k = 0; k < 6; ++k) (void)hipFree(h->pvz[k]);
   (void)hipFree(h->stage);
   (void)hipFree(h->dstats);
   (void)hipFree(h->dcounter);
@@ -962,8 +1025,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->sort_work, n)) || (rc = dev_alloc(h, &h->unordered, (size_t)h->ncell_pad / 32)) ||
       (rc = dev_alloc(h, &h->cell_count, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
-      (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->scan_status, (size_t)h->nscan)) ||
-      (rc = dev_alloc(h, &h->scan_ticket, 1)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
+      (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
       (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 8)) || (rc = dev_alloc(h, &h->dn, 16)) ||
       (rc = dev_alloc(h, &h->pack_counts, (size_t)4 * ((n + kPackChunk - 1) / kPackChunk))))
     return bail(rc);
@@ -993,11 +1055,6 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       return bail(DSL_ERR_DEVICE);
     }
   }
-  h->tg.tnx = (h->c.dims[0] + kTB - 1) / kTB;
-  h->tg.tny = (h->c.dims[1] + kTB - 1) / kTB;
-  h->tg.tnz = (h->c.dims[2] + kTB - 1) / kTB;
-  h->tg.ntiles = h->tg.tnx * h->tg.tny * h->tg.tnz;
-  if (const char* e = std::getenv("DSL_SCAN_ONEPASS")) h->scan_onepass = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_DENSITY_PAIR")) h->density_pair = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_QTILED")) h->pci_qtiled = std::atoi(e) != 0;
   if (const char* e = std::getenv("DSL_PCI_QPAIR")) h->pci_qpair = std::atoi(e) != 0;
@@ -1007,25 +1064,22 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     h->pci_bin_mode = m < 0 ? -1 : (m > 0 ? 1 : 0);
   }
   if (const char* e = std::getenv("DSL_PERSISTENT_BLOCKS")) h->max_persistent_blocks = std::atoi(e);
-  {  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
-    int bx = 8, by = 4, bz = 4;
-    if (const char* e = std::getenv("DSL_TILE_BOX")) {  // "bx,by,bz" (A/B runs); "0" = the tile grid's linear order
-      bx = by = bz = 0;
-      if (std::sscanf(e, "%d,%d,%d", &bx, &by, &bz) < 3 || bx <= 0 || by <= 0 || bz <= 0) bx = by = bz = 0;
-    }
-    h->tg.bx = bx;
-    h->tg.by = by;
-    h->tg.bz = bz;
-    h->tg.nbx = bx ? (h->tg.tnx + bx - 1) / bx : 0;
-    h->tg.nby = bx ? (h->tg.tny + by - 1) / by : 0;
-    const long long nlist = bx ? (long long)h->tg.nbx * h->tg.nby * ((h->tg.tnz + bz - 1) / bz) * (bx * by * bz) : h->tg.ntiles;
-    if (nlist > 0x7fffffffLL) return bail(fail(h, DSL_ERR_INVALID, "tile grid too large"));
-    h->tg.nlist = (int)nlist;
+  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
+  if (const char* e = std::getenv("DSL_TILE_BOX")) {  // "bx,by,bz" (A/B runs); "0" = the tile grid's linear order
+    int bx = 0, by = 0, bz = 0;
+    if (std::sscanf(e, "%d,%d,%d", &bx, &by, &bz) < 3 || bx <= 0 || by <= 0 || bz <= 0) bx = by = bz = 0;
+    h->tile_box[0] = bx;
+    h->tile_box[1] = by;
+    h->tile_box[2] = bz;
   }
-  if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->tg.ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
+  if ((rc = set_tile_grid(h))) return bail(rc);
+  // (room for the skin step's grid as well: wider cells, but tiles of 3 cell layers in z -- at most 4/3 of these tiles)
+  h->alloc_ntiles = h->tg.tnx * h->tg.tny * ((h->c.dims[2] + 2) / 3);
+  if (h->alloc_ntiles < h->tg.ntiles) h->alloc_ntiles = h->tg.ntiles;
+  if ((rc = dev_alloc(h, &h->tiles, (size_t)kTileLists * h->alloc_ntiles)) || (rc = dev_alloc(h, &h->n_tiles, 8))) return bail(rc);
   // a non-empty tile holds a particle: at most min(tiles, capacity) tables (1.5 KB each)
-  if ((rc = dev_alloc(h, &h->tile_desc_of, (size_t)kTileLists * h->tg.ntiles)) ||
-      (rc = dev_alloc(h, &h->tile_desc, (size_t)std::min(h->tg.ntiles, h->cap) * kMetaInts)))
+  if ((rc = dev_alloc(h, &h->tile_desc_of, (size_t)kTileLists * h->alloc_ntiles)) ||
+      (rc = dev_alloc(h, &h->tile_desc, (size_t)std::min(h->alloc_ntiles, h->cap) * kMetaInts)))
     return bail(rc);
   if (!h->lsh && (rc = dev_alloc(h, &h->nmask, (size_t)kMaskWords * n))) return bail(rc);
   // NewParticleArray zero-fills every slice (particle_array.go:18-33)
@@ -1051,6 +1105,9 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   }
   h->forces_uniform = false;  // uploaded / zero forces are honoured until the first Update
   h->press_zero = true;
+  // the skin step is the default where it pays: DSL_MATH_FAST, enough particles for a step to outweigh the ~40 us of
+  // gated launches it adds (measured break-even near a million; dsl_set_option(DSL_OPT_SKIN) overrides)
+  if (params->math_mode == DSL_MATH_FAST && h->n >= kSkinDefaultParticles) h->skin = kSkinDefault;
   *out = h;
   return DSL_OK;
 }
@@ -1538,15 +1595,228 @@ int dsl_field_interpolate(dsl_handle* h, int scalar_buffer, const float* host_po
   return DSL_OK;
 }
 
+namespace {
+// ---------------------------------------------------------------------------------------
+// the skin step (kernels_skin.hpp): neighbour lists that live for several steps
+// ---------------------------------------------------------------------------------------
+// Every kSkinLook skin steps the host reads one word of the device state: has the flow outrun the skin (half of the last
+// 16 steps rebuilt)?  Then the lists cost more than they save and the step goes back to sorting and sweeping every step
+// for kSkinRetry steps.  Both happen at step counts fixed in advance: results do not depend on timing or on how the
+// steps were grouped into calls.
+constexpr int kSkinLook = 32;
+constexpr int kSkinRetry = 2048;
+
+bool skin_usable(const dsl_handle* h) {
+  return h->skin > 0.0f && h->steps >= h->skin_retry_at && h->prm.math_mode == DSL_MATH_FAST && !h->lsh && h->c.slab_axis < 0 && !h->c.n_ptr && h->nb == 0 &&
+         !h->pci_active && h->c.xsph_eps == 0.0f && h->c.st_kappa == 0.0f && use_tiled(h) && h->nmask != nullptr &&
+         (h->c.wcsph_pressure_force != 0 || h->c.wcsph_viscosity != 0);
+}
+
+int skin_alloc(dsl_handle* h) {
+  int rc = DSL_OK;
+  if (!h->skin_state && (rc = dev_alloc(h, &h->skin_state, 1))) return rc;
+  if (!h->lists && (rc = dev_alloc(h, &h->lists, (size_t)kLMaxChunks * h->cap))) return rc;
+  for (int k = 0; k < 6; ++k)
+    if (!h->pvz[k] && (rc = dev_alloc(h, &h->pvz[k], (size_t)h->cap))) return rc;
+  return DSL_OK;
+}
+
+// from the plain state into skin steps: wide cells, the device state seeded with the host's view, a rebuild forced
+int skin_enter(dsl_handle* h) {
+  if (int rc = skin_alloc(h)) return rc;
+  if (h->sort_scratch_dirty) {
+    HIP_TRY(h, hipMemsetAsync(h->cell_count, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+    if (h->unordered) HIP_TRY(h, hipMemsetAsync(h->unordered, 0, sizeof(unsigned int) * (size_t)(h->ncell_pad / 32), h->stream));
+    h->sort_scratch_dirty = false;
+  }
+  if (int rc = set_cell_edge(h, h->c.h * (1.0f + h->skin), 3)) return rc;
+  if (h->tg.ntiles > h->alloc_ntiles) {  // (cannot happen for skin <= 0.2: wider cells, 4/3 the layers)
+    (void)set_cell_edge(h, h->c.h);
+    return fail(h, DSL_ERR_INVALID, "skin step: the tile grid outgrew its allocation");
+  }
+  SkinState init{};
+  init.ids_sel = h->cur_ids;
+  init.force = 1;
+  init.budget = 0.5f * h->skin * h->c.h * (1.0f - 1.0e-3f);
+  init.dt = h->c.dt;
+  HIP_TRY(h, hipMemcpyAsync(h->skin_state, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // (`init` lives on this stack frame; entering is rare)
+  h->skin_live = true;
+  h->skin_live_steps = 0;
+  return DSL_OK;
+}
+
+int skin_step(dsl_handle* h) {
+  const DevConsts& c = h->c;
+  SkinState* st = h->skin_state;
+  const SkinGate gate{st};
+  const int n = h->n;
+  const int X = h->cur_pv, Y = X ^ 1;
+  const CSoa3 pX = cpos(h), vX = cvel(h);
+  const CSoa3 pZ{h->pvz[0], h->pvz[1], h->pvz[2]}, vZ{h->pvz[3], h->pvz[4], h->pvz[5]};
+  const bool ordered = !h->prm.sort_unordered;
+  hipLaunchKernelGGL(k_skin_decide, dim3(1), dim3(1), 0, h->stream, st);
+  HIP_TRY(h, hipGetLastError());
+  // the rebuild chain: launched every step, every kernel returns at once unless this step rebuilds
+  int rc = timed(h, DSL_K_CELL_RANK, [&] {
+    hipLaunchKernelGGL(k_cell_rank<false>, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, pX.x, pX.y, pX.z,
+                       ordered ? h->ids[0] : nullptr, h->rank, h->cell_count, h->unordered, nullptr, nullptr,
+                       ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0, gate, h->ids[1]);
+  });
+  if (rc) return rc;
+  rc = timed(h, DSL_K_SCAN, [&] {
+    hipLaunchKernelGGL(k_scan_sums, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums, h->dstats,
+                       h->n_tiles, gate);
+    hipLaunchKernelGGL(k_scan_apply, dim3(h->nscan), dim3(kBlock), 0, h->stream, h->cell_count, h->block_sums,
+                       h->cell_start, h->dstats, gate);
+  });
+  if (rc) return rc;
+  ScatterArrays a{};
+  for (int k = 0; k < 6; ++k) {
+    a.src[k] = h->pv[X][k];
+    a.dst[k] = h->pvz[k];
+  }
+  a.nf = 6;
+  a.ids_src = h->ids[0];  // (the kernels swap the two by the device's ids_sel)
+  a.ids_dst = h->ids[1];
+  ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work), nullptr,
+                  ordered ? h->cell_keys : nullptr, h->dcounter + 3};
+  rc = timed(h, DSL_K_SCATTER, [&] {
+    hipLaunchKernelGGL(k_scatter, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate);
+    if (ordered)
+      hipLaunchKernelGGL(k_scatter_ordered, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
+                         h->stream, c, a, so, pX, h->rank, h->cell_start, gate);
+  });
+  if (rc) return rc;
+  rc = timed(h, DSL_K_TILE_LIST, [&] {
+    hipLaunchKernelGGL(k_tile_list, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->cell_start, h->tiles,
+                       h->n_tiles, h->n_tiles + 5, nullptr, h->tile_desc_of, h->unordered, h->ncell_pad / 32, h->dcounter + 3,
+                       gate);
+    hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, c, h->tg, h->cell_start,
+                       h->cell_start, h->tiles, h->n_tiles, h->tile_desc, nullptr, kTCap, gate);
+  });
+  if (rc) return rc;
+  // candidates within h (1 + skin) of the sorted positions -> masks -> lists
+  const double reach = 1.0 + (double)h->skin;
+  const float wide_thr = (float)(1.0 - reach * reach * 1.0004 - 1.0e-4);
+  rc = timed(h, DSL_K_NEIGH_LISTS, [&] {
+    hipLaunchKernelGGL((k_density_pair<false, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
+                       h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pZ, h->rho, h->pterm, h->nmask,
+                       h->cap, wide_thr, gate);
+    hipLaunchKernelGGL((k_density_pair<true, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
+                       h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pZ, h->rho, h->pterm, h->nmask,
+                       h->cap, wide_thr, gate);
+    hipLaunchKernelGGL(k_list_build, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+                       h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pZ, wide_thr);
+  });
+  if (rc) return rc;
+  // the step itself: densities and the fused force + integrate over the lists
+  rc = timed(h, DSL_K_DENSITY, [&] {
+    hipLaunchKernelGGL(k_density_list, dim3(persistent_grid(h, 3)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+                       h->n_tiles, h->tile_desc, h->cell_start, st, pX, pZ, h->lists, h->cap, h->rho, h->pterm);
+  });
+  if (rc) return rc;
+  const Soa3 po = mpos(h, Y), vo = mvel(h, Y);
+  const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
+  rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
+    dim3 g(persistent_grid(h, 2)), b(kLBlock);
+#define DSL_LAUNCH_FL(GG, VV)                                                                                             \
+  hipLaunchKernelGGL((k_force_list<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, h->tile_desc,       \
+                     h->cell_start, st, pX, vX, pZ, vZ, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats)
+    if (G && V) DSL_LAUNCH_FL(true, true);
+    else if (G) DSL_LAUNCH_FL(true, false);
+    else DSL_LAUNCH_FL(false, true);
+#undef DSL_LAUNCH_FL
+  });
+  if (rc) return rc;
+  h->cur_pv = Y;
+  h->masks_valid = false;
+  h->grid_valid = false;
+  h->dens_fresh = h->dens_held = true;
+  h->forces_uniform = true;
+  h->press_zero = true;
+  h->skin_live_steps += 1;
+  if (h->skin_live_steps % kSkinLook == 0) {
+    int give_up = 0;
+    HIP_TRY(h, hipMemcpyAsync(&give_up, &st->give_up, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (give_up) {
+      h->skin_retry_at = h->steps + 1 + kSkinRetry;
+      h->skin_suspensions += 1;
+      return skin_settle(h);
+    }
+  }
+  return DSL_OK;
+}
+
+// back to the plain state: which slot -> particle map is current is the device's knowledge (one small read)
+int skin_settle(dsl_handle* h) {
+  SkinState s{};
+  HIP_TRY(h, hipMemcpyAsync(&s, h->skin_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->cur_ids = s.ids_sel & 1;
+  h->skin_steps_total += s.n_steps;
+  h->skin_rebuilds_total += s.n_rebuilds;
+  h->skin_list_overflow |= s.list_overflow != 0;
+  h->skin_live = false;
+  h->dens_held = false;  // (rho / pterm are in slot order, but nothing downstream may rely on lists any more)
+  h->dens_fresh = false;
+  return set_cell_edge(h, h->c.h);
+}
+
+}  // namespace
+
 int dsl_wcsph_step(dsl_handle* h, int nsteps) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_ONLY(h);
   for (int s = 0; s < nsteps; ++s) {
+    // (forces that differ from force_reset -- uploaded ones, before the first Update -- take one plain step first)
+    if (skin_usable(h) && (h->skin_live || h->forces_uniform)) {
+      if (!h->skin_live)
+        if (int rc = skin_enter(h)) return rc;
+      if (int rc = skin_step(h)) return rc;
+      h->steps++;
+      continue;
+    }
+    if (h->skin_live)
+      if (int rc = skin_settle(h)) return rc;
     if (int rc = build_grid(h, false)) return rc;  // NN(): geometric neighbour rule -> every step
     if (int rc = density_pass(h)) return rc;        // DensityAll   wcsph.go:18
     if (int rc = force_integrate(h)) return rc;     // ExternalAll, PressureAll, Update wcsph.go:19-21
     h->steps++;
   }
   return DSL_OK;
+}
+
+int dsl_set_option(dsl_handle* h, int option, double value) {
+  CHECK_HANDLE(h);
+  switch (option) {
+    case DSL_OPT_SKIN:
+      // (0.2: the wide sweep's LDS image holds (6 cells x 2 (1 + s) particles)^3 <= kTCapWide records)
+      if (!(value >= 0.0 && value <= 0.2)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_SKIN is a fraction of h in [0, 0.2]");
+      h->skin = (float)value;
+      h->skin_retry_at = 0;
+      return DSL_OK;
+    default:
+      return fail(h, DSL_ERR_INVALID, "dsl_set_option: unknown or read-only option");
+  }
+}
+
+int dsl_get_option(dsl_handle* h, int option, double* value) {
+  CHECK_HANDLE_ONLY(h);
+  if (!value) return fail(h, DSL_ERR_INVALID, "dsl_get_option: null output");
+  SkinState s{};
+  if (h->skin_live && (option == DSL_OPT_SKIN_STEPS || option == DSL_OPT_SKIN_REBUILDS || option == DSL_OPT_SKIN_LIST_OVERFLOW)) {
+    HIP_TRY(h, hipMemcpyAsync(&s, h->skin_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  switch (option) {
+    case DSL_OPT_SKIN: *value = h->skin; return DSL_OK;
+    case DSL_OPT_SKIN_STEPS: *value = (double)(h->skin_steps_total + s.n_steps); return DSL_OK;
+    case DSL_OPT_SKIN_REBUILDS: *value = (double)(h->skin_rebuilds_total + s.n_rebuilds); return DSL_OK;
+    case DSL_OPT_SKIN_LIST_OVERFLOW: *value = (h->skin_list_overflow || s.list_overflow != 0) ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_SKIN_SUSPENSIONS: *value = (double)h->skin_suspensions; return DSL_OK;
+    default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
+  }
 }
 
 int dsl_pcisph_begin(dsl_handle* h) {
@@ -2607,7 +2877,7 @@ int dsl_reset_forces(dsl_handle* h) {
 }
 
 int dsl_get_stats(dsl_handle* h, dsl_stats* out) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_ONLY(h);
   if (!out) return fail(h, DSL_ERR_INVALID, "null out");
   DevStats d{};
   HIP_TRY(h, hipMemcpyAsync(&d, h->dstats, sizeof(d), hipMemcpyDeviceToHost, h->stream));
@@ -2624,25 +2894,22 @@ int dsl_get_stats(dsl_handle* h, dsl_stats* out) {
   for (int a = 0; a < 3; ++a) out->grid_dims[a] = h->c.dims[a];
   out->grid_cells = h->c.ncell;
   out->max_cell_count = d.max_cell_count;
-  if (d.scan_stuck)
-    return fail(h, DSL_ERR_DEVICE, "neighbour build: the one-launch prefix scan gave up waiting for a tile (device fault?); "
-                                   "the state is void -- DSL_SCAN_ONEPASS=0 selects the three-launch scan");
   return DSL_OK;
 }
 
 int dsl_sync(dsl_handle* h) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_ONLY(h);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return DSL_OK;
 }
 
 int dsl_timing_enable(dsl_handle* h, int on) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_ONLY(h);
   h->timing = on < 0 ? 0 : (on > 2 ? 1 : on);
   return DSL_OK;
 }
 int dsl_timing_reset(dsl_handle* h) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_ONLY(h);
   if (int rc = drain_timing(h)) return rc;
   for (int k = 0; k < DSL_K_COUNT; ++k) {
     h->total_ms[k] = 0.0;
@@ -2651,7 +2918,7 @@ int dsl_timing_reset(dsl_handle* h) {
   return DSL_OK;
 }
 int dsl_timing_get(dsl_handle* h, int kid, double* avg_ms, int64_t* launches) {
-  CHECK_HANDLE(h);
+  CHECK_HANDLE_ONLY(h);
   if (kid < 0 || kid >= DSL_K_COUNT) return fail(h, DSL_ERR_INVALID, "bad kernel id");
   if (int rc = drain_timing(h)) return rc;
   if (avg_ms) *avg_ms = h->launches[kid] ? h->total_ms[kid] / (double)h->launches[kid] : 0.0;

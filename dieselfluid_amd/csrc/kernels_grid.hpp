@@ -59,7 +59,6 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   // (skin step: `ids` is map 0, `ids_alt` map 1; the device state names the map that is current AFTER this rebuild,
   // so the one to read -- the order before the sort -- is the other)
   if (gate.st != nullptr && ids != nullptr && gate.st->ids_sel == 0) ids = ids_alt;
-  const int i = blockIdx.x * kBlock + threadIdx.x;
   // the small counters of the later kernels of this build (the fullest-cell statistic of the scan, the tile-list
   // lengths): cleared here, at the head of the build, when the one-launch scan is in use (stats != nullptr)
   if (stats != nullptr && blockIdx.x == 0) {
@@ -67,8 +66,12 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
     if (n_tiles != nullptr && threadIdx.x < 8) n_tiles[threadIdx.x] = 0;
   }
   const int lane = threadIdx.x & (kWave - 1);
-  int cell = -1, id = 0;
   const int n = live_n(c);
+  // (grid-stride: the skin step launches a capped grid -- on the steps that do not rebuild, all a launch does is find
+  // its gate closed, and 62,500 workgroups doing that took 14 us; every other caller's grid covers n in one trip)
+  for (int first = blockIdx.x * kBlock; first < n; first += gridDim.x * kBlock) {
+  const int i = first + threadIdx.x;
+  int cell = -1, id = 0;
   if (i < n) {
     cell = sort_cell(c, px[i], py[i], pz[i]);
     if (ids) id = ids[i];
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   if (cell_keys != nullptr && i < n && cell >= 0 && cell != c.ncell) {
     if (r < kCellKeys) cell_keys[(size_t)cell * kCellKeys + r] = id;
     else *overfull = 1;  // (rare: benign race, every writer stores 1)
+  }
   }
 }
 
@@ -212,118 +216,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
     atomicMax(&stats->max_cell_count, mx);
 }
 
-// The same exclusive prefix in ONE launch (decoupled look-back): every block takes a ticket, scans its 4096-cell tile,
-// publishes the tile's sum, then adds up the sums its predecessors have published until it meets one that already
-// knows its own prefix.  The counts are read once (the three-launch form reads them twice) and two launches go.
-// MEASURED AND NOT USED (DSL_SCAN_ONEPASS=1 selects it): 0.46 ms against 0.077 at 16.4M cells, 0.112 against 0.035 at
-// 4M, 0.024 against 0.018 at 1M.  Every tile of the grid is resident at once here, so the prefixes travel down one chain
-// of ~60 look-back windows, each an agent-scope round trip (the XCDs' L2s are not coherent with each other).
-//   status[tile] = value | (generation * 4 + flag) << 32, flag 1 = the tile's own sum, 2 = its inclusive prefix;
-//   the generation is ticket / nb of an ever-growing 64-bit ticket counter, so nothing is ever cleared and a
-//   replayed hipGraph needs no new arguments.
-// Forward progress: a block only waits for blocks with smaller tickets, and those are running (they hold a ticket).
-// The wait is bounded all the same (a fault elsewhere must not become a hung GPU): stats->scan_stuck is raised and the
-// build's result is then garbage, which the host reports.
-__global__ __launch_bounds__(kBlock) void k_scan_onepass(int* __restrict__ count, int* __restrict__ cell_start,
-                                                         unsigned long long* __restrict__ status,
-                                                         unsigned long long* __restrict__ ticket_counter, int nb,
-                                                         DevStats* stats) {
-  __shared__ int lds[kBlock / kWave];
-  __shared__ unsigned long long s_ticket;
-  __shared__ int s_prefix;
-  if (threadIdx.x == 0) s_ticket = atomicAdd(ticket_counter, 1ull);
-  __syncthreads();
-  const unsigned long long ticket = s_ticket;
-  const int tile = (int)(ticket % (unsigned long long)nb);
-  const unsigned int gen = (unsigned int)((ticket / (unsigned long long)nb) & 0x3fffffffull) + 1u;
-  int4* src = reinterpret_cast<int4*>(count + (size_t)tile * kScanTile);
-  int4* dst = reinterpret_cast<int4*>(cell_start + (size_t)tile * kScanTile);
-  int4 v[4];
-  int s[4], tsum = 0, mx = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    v[k] = src[k * kBlock + threadIdx.x];
-    s[k] = (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    mx = max(max(mx, max(v[k].x, v[k].y)), max(v[k].z, v[k].w));
-  }
-  // the four sub-tiles' block scans (sub-tile k holds cells k*1024 .. k*1024+1023 of the tile)
-  int ex[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int total;
-    ex[k] = tsum + block_exclusive_scan(s[k], lds, total);
-    tsum += total;
-  }
-  auto pack = [&](int value, unsigned int flag) {
-    return (unsigned long long)(unsigned int)value | ((unsigned long long)(gen * 4u + flag) << 32);
-  };
-  if (threadIdx.x < kWave) {  // wave 0 publishes and looks back
-    const int lane = threadIdx.x;
-    if (tile == 0) {
-      if (lane == 0) {
-        __hip_atomic_store(&status[0], pack(tsum, 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        s_prefix = 0;
-      }
-    } else {
-      if (lane == 0) __hip_atomic_store(&status[tile], pack(tsum, 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      int running = 0;
-      bool done = false;
-      for (int look = tile - 1; !done && look >= 0; look -= kWave) {
-        const int idx = look - lane;  // lane 0 = the nearest predecessor
-        unsigned long long w = 0ull;
-        unsigned int tag = 0u;
-        int spins = 0;
-        bool stuck = false;
-        for (;;) {
-          if (idx >= 0) {
-            w = __hip_atomic_load(&status[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            tag = (unsigned int)(w >> 32);
-          }
-          const bool ready = idx < 0 || (tag >> 2) == gen;
-          if (__builtin_amdgcn_ballot_w64(!ready) == 0ull) break;
-          if (++spins > (1 << 22)) {  // (~seconds: never in a healthy run)
-            stuck = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (stuck) {
-          if (lane == 0) stats->scan_stuck = 1;
-          break;
-        }
-        const bool inclusive = idx >= 0 && (tag & 3u) == 2u;
-        const unsigned long long incl = __builtin_amdgcn_ballot_w64(inclusive);
-        const int first = incl ? __builtin_ctzll(incl) : kWave;  // nearest predecessor that knows its prefix
-        int contrib = (idx >= 0 && lane <= first) ? (int)(unsigned int)w : 0;
-        for (int o = kWave / 2; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, kWave);
-        running += contrib;
-        done = incl != 0ull;
-      }
-      if (lane == 0) {
-        s_prefix = running;
-        __hip_atomic_store(&status[tile], pack(running + tsum, 2u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-  __syncthreads();
-  const int carry = s_prefix;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    // (most of the box is empty: only counts that are there are cleared)
-    if ((v[k].x | v[k].y | v[k].z | v[k].w) != 0) src[k * kBlock + threadIdx.x] = make_int4(0, 0, 0, 0);
-    int4 o;
-    o.x = carry + ex[k];
-    o.y = o.x + v[k].x;
-    o.z = o.y + v[k].y;
-    o.w = o.z + v[k].z;
-    dst[k * kBlock + threadIdx.x] = o;
-  }
-  for (int off = kWave / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, kWave));
-  if (stats != nullptr && (threadIdx.x & (kWave - 1)) == 0 && mx > 0 &&
-      mx > __hip_atomic_load(&stats->max_cell_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-    atomicMax(&stats->max_cell_count, mx);
-}
-
 // ---------------------------------------------------------------------------------
 // counting-sort scatter of every live SoA array (positions, velocities, and when they
 // are materialised the forces and the PCISPH predictor state) plus the slot->particle map
@@ -358,33 +250,36 @@ struct ScatterOrder {
 // same-address atomics per 16M-particle build serialise in L2 and took 2.8 ms once the flow had
 // developed.  A byte per particle costs 32 MB of traffic and no atomics.)
 
-__device__ __forceinline__ void scatter_move(const ScatterArrays& a, const ScatterOrder& o, int i, int d, int id) {
-  a.ids_dst[d] = id;
+__device__ __forceinline__ void scatter_move(const ScatterArrays& a, const ScatterOrder& o, int i, int d, int id,
+                                             int* __restrict__ ids_dst) {
+  ids_dst[d] = id;
   for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
   if (o.dest) o.dest[i] = d;
 }
 
 // `pos`: the unsorted positions the ranks were computed from
 // (skin step: the host passes map 0 as a.ids_src and map 1 as a.ids_dst; the device state names the map that is current
-// AFTER this rebuild -- the sort's destination)
-__device__ __forceinline__ void skin_ids(ScatterArrays& a, const SkinGate& gate) {
-  if (gate.st != nullptr && gate.st->ids_sel == 0) {  // the new current map is 0: scatter 1 -> 0
-    const int* s = a.ids_dst;
-    a.ids_dst = const_cast<int*>(a.ids_src);
-    a.ids_src = s;
-  }
+// AFTER this rebuild -- the sort's destination.  The kernel argument itself stays untouched: written to, the whole
+// struct moves from the kernarg segment into scratch memory and the scatter takes 5 x as long.)
+struct ScatterIds {
+  const int* src;
+  int* dst;
+};
+__device__ __forceinline__ ScatterIds skin_ids(const ScatterArrays& a, const SkinGate& gate) {
+  if (gate.st != nullptr && gate.st->ids_sel == 0) return ScatterIds{a.ids_dst, const_cast<int*>(a.ids_src)};  // 1 -> 0
+  return ScatterIds{a.ids_src, a.ids_dst};
 }
 __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr}) {
   if (gate.closed()) return;
-  skin_ids(a, gate);
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= live_n(c)) return;
+  const ScatterIds ids = skin_ids(a, gate);
+  const int n = live_n(c);
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {  // (grid-stride: see k_cell_rank)
   bool later = false;
   const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
   if (cell != c.ncell) {  // (a stale ghost is dropped)
-    const int id = a.ids_src[i];
+    const int id = ids.src[i];
     const int s = cell_start[cell], r = rank[i];
     int d = s + r;
     later = o.unordered != nullptr && ((o.unordered[cell >> 5] >> (cell & 31)) & 1u);
@@ -405,9 +300,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
       }
     }
     if (later) o.keys[d] = id;
-    else scatter_move(a, o, i, d, id);
+    else scatter_move(a, o, i, d, id, ids.dst);
   }
   if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later ? 1 : 0;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
@@ -415,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, Scatter
                                                             const int* __restrict__ cell_start,
                                                             SkinGate gate = SkinGate{nullptr}) {
   if (gate.closed()) return;
-  skin_ids(a, gate);
+  const ScatterIds ids = skin_ids(a, gate);
   if (o.cell_keys != nullptr) {
     // fallback of the one-pass ordering: only the marked cells with more than kCellKeys members are left, and only
     // if k_cell_rank has seen such a cell at all.  A small grid strides over the particles.
@@ -426,20 +322,20 @@ __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, Scatter
       if (cell == c.ncell) continue;
       const int s = cell_start[cell], e = cell_start[cell + 1];
       if (e - s <= kCellKeys || !((o.unordered[cell >> 5] >> (cell & 31)) & 1u)) continue;
-      const int id = a.ids_src[i], mine = s + rank[i];
+      const int id = ids.src[i], mine = s + rank[i];
       int below = 0;
       for (int k = s; k < e; ++k) {
         const int key = o.keys[k];
         below += (key < id || (key == id && k < mine)) ? 1 : 0;
       }
-      scatter_move(a, o, i, s + below, id);
+      scatter_move(a, o, i, s + below, id, ids.dst);
     }
     return;
   }
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c) || !o.later[i]) return;
   const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
-  const int id = a.ids_src[i];
+  const int id = ids.src[i];
   const int s = cell_start[cell], e = cell_start[cell + 1], mine = s + rank[i];
   int below = 0;
   // eight ids per trip, all eight loads in flight together (a cell holds ~8)
@@ -450,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, Scatter
 #pragma unroll
     for (int u = 0; u < 8; ++u) below += (key[u] < id || (key[u] == id && k0 + u < mine)) ? 1 : 0;
   }
-  scatter_move(a, o, i, s + below, id);
+  scatter_move(a, o, i, s + below, id, ids.dst);
 }
 
 // dst[dest[i]] = src[i]: a derived per-particle array follows the sort

@@ -92,6 +92,10 @@ struct TileGrid {
   // tiles of a box fetch 1.3 x its particles from HBM, where 128 tiles of the linear order (a 32 x 4 x 1 sheet)
   // fetch 1.7 x and share nothing with the sheets above and below.  bx = 0: linear order.
   int bx, by, bz, nbx, nby, nlist;  // nlist = list threads = boxes * box size
+  // cell layers a tile owns along z: kTB, or 3 for the skin step (kernels_skin.hpp) -- its cells are h (1 + s) wide, and
+  // 4 x 4 x 3 of them hold the ~512 targets and ~1900 staged records that 4 x 4 x 4 cells of edge h hold: the tile
+  // tables keep their shape (interior rows 12..15 and staged rows 30..35 are simply empty)
+  int tbz;
 };
 __device__ __forceinline__ int tile_of_list_thread(const TileGrid& tg, int t) {
   if (tg.bx == 0) return t < tg.ntiles ? t : -1;
@@ -153,8 +157,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(DevConsts c, TileGrid tg, 
     for (int dz = 0; dz < kTB; ++dz)
 #pragma unroll
       for (int dy = 0; dy < kTB; ++dy) {
-        const int z = tz * kTB + dz, y = ty * kTB + dy;
-        if (z < nz && y < ny) {
+        const int z = tz * tg.tbz + dz, y = ty * kTB + dy;
+        if (dz < tg.tbz && z < nz && y < ny) {
           const int row = (z * ny + y) * nx;
           cnt += cell_start[row + xb] - cell_start[row + xa];
         }
@@ -224,8 +228,8 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
   const int tx = tile % tg.tnx, ty = (tile / tg.tnx) % tg.tny, tz = tile / (tg.tnx * tg.tny);
   const int nx = c.dims[0], ny = c.dims[1], nz = c.dims[2];
   const int ry = tid % kTH, rz = tid / kTH;
-  const int y = ty * kTB - 1 + ry, z = tz * kTB - 1 + rz;
-  if (y >= 0 && y < ny && z >= 0 && z < nz) {
+  const int y = ty * kTB - 1 + ry, z = tz * tg.tbz - 1 + rz;
+  if (y >= 0 && y < ny && z >= 0 && z < nz && rz <= tg.tbz + 1) {
     const int row = (z * ny + y) * nx;
     // cells tx*4-1 .. tx*4+4, clamped to the grid: out-of-grid cells are empty
 #pragma unroll
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
   const int lane = threadIdx.x;
   const int ry = lane % kTH, rz = lane / kTH;
   const bool row = lane < kTRows;
-  const bool interior = row && ry >= 1 && ry <= kTB && rz >= 1 && rz <= kTB;
+  const bool interior = row && ry >= 1 && ry <= kTB && rz >= 1 && rz <= tg.tbz;
   const bool queries = target_start != cell_start;
   // (two tiles per trip: the second one's loads travel under the first one's sums)
   auto table = [&](int item, int tile, const TileSetupRegs& r, const TileSetupRegs& q) {
@@ -312,7 +316,9 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
 #pragma unroll
       for (int lx = 1; lx <= kTB; ++lx)
         out->run[lane * kTB + lx - 1] = (lds0 + (r.s[lx - 1] - r.s[0])) | ((lds0 + (r.s[lx + 2] - r.s[0])) << 16);
-      if (interior) {
+      // (a tile of fewer than kTB cell layers -- TileGrid::tbz -- still fills all 16 entries: the layers it does not own
+      // are rows without targets, and the target lookup's binary search runs over all of them)
+      if (ry >= 1 && ry <= kTB && rz >= 1 && rz <= kTB) {
         const int ir = (rz - 1) * kTB + (ry - 1), t0 = tinc - tv;  // the row's first target
         out->tprefix[ir] = t0;
         out->pprefix[ir] = pinc - pv;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
         out->tile = tile;
         out->centre[0] = __float_as_int(c.gmin[0] + ((tile % tg.tnx) * kTB + 0.5f * kTB) * c.cell);
         out->centre[1] = __float_as_int(c.gmin[1] + (((tile / tg.tnx) % tg.tny) * kTB + 0.5f * kTB) * c.cell);
-        out->centre[2] = __float_as_int(c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * kTB + 0.5f * kTB) * c.cell);
+        out->centre[2] = __float_as_int(c.gmin[2] + ((tile / (tg.tnx * tg.tny)) * tg.tbz + 0.5f * tg.tbz) * c.cell);
       }
     }
   };
@@ -1202,18 +1208,17 @@ __device__ __forceinline__ PairSlot pair_slot(const TileMeta& m, int u) {
 
 // WIDE (the skin step's candidate sweep, kernels_skin.hpp): the grid's cells are h (1 + s) wide, the masks take every
 // candidate within that distance (`wide_thr` = 1 - (1 + s)^2, less a rounding margin: the test is 1 - r^2/h^2 > wide_thr),
-// densities are not formed here (k_density_list forms them, every step, from the lists these masks become), and the
-// LDS image is the wider kTCapWide records.
-constexpr int kTCapWide = 3072;  // 6 cells x 1.1 x 2 particles per h = 13.2 lattice planes per axis: up to 14^3 = 2744
+// densities are not formed here (k_density_list forms them, every step, from the lists these masks become); the tiles
+// are 4 x 4 x 3 of those cells (TileGrid::tbz), whose image fits the same kTCap records.
 template <bool SHARE, bool WIDE = false>
-__global__ __launch_bounds__(kPBlock, WIDE ? 3 : 4) void k_density_pair(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+__global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                              const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                              const int* __restrict__ cell_start, Bnd bnd, CSoa3 p,
                                                              float* __restrict__ rho, float* __restrict__ pterm,
                                                              unsigned int* __restrict__ nmask, int mstride,
                                                              float wide_thr = 0.0f, SkinGate gate = SkinGate{nullptr}) {
   __shared__ TileMeta metas[2];
-  __shared__ float4 A[WIDE ? kTCapWide : kTCap];
+  __shared__ float4 A[kTCap];
   const int tid = threadIdx.x;
   if (gate.closed()) return;
   if (c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;

@@ -85,7 +85,7 @@ struct DevStats {
   int pci_done;
   int max_cell_count;
   int band_missed;  // split slab step: an interior particle moved further than the split margin
-  int scan_stuck;   // k_scan_onepass gave up waiting for a predecessor tile (never in a healthy run): the build is void
+  int reserved0_;
   // slab mode, PCISPH: a DensityF query point (the predictor's position, which the reference never re-synchronises)
   // lies more than h beyond a slab plane, i.e. outside what the 2h ghost band covers: its sum is missing neighbours
   // that live on another rank, and the run no longer equals the single-domain run (dsl_slab_status[1], bit 1)
@@ -99,14 +99,16 @@ struct DevStats {
 struct SkinState {
   int rebuild;      // this step rebuilds: counting sort, candidate sweep, lists
   int ids_sel;      // which of the two slot -> particle maps is current (a rebuild flips it on the device)
-  float disp;       // upper bound of any particle's displacement since the lists were built
-  unsigned int step_vmax_bits;  // max |v|^2 of the step just integrated (bits of a non-negative float)
+  float disp;       // the largest displacement of any particle since the lists were built (as of the last decision)
+  unsigned int disp2_bits;  // max |x - x_build|^2 after the step just integrated (bits of a non-negative float)
   int force;        // host request: rebuild at the next step whatever the bound says
   int n_steps, n_rebuilds;
   int list_overflow;  // targets whose list did not fit (they take the global-memory sweep)
   float budget;     // s h / 2, less a rounding margin
   float dt;
-  int pad_[6];
+  unsigned int history;  // bit k: the step k steps ago rebuilt
+  int give_up;      // half of the last 16 steps rebuilt: the flow outruns the skin, the lists no longer pay (host: suspend)
+  int pad_[4];
 };
 // the gate every kernel of the rebuild chain takes (st == nullptr: no gate, the kernel always runs)
 struct SkinGate {

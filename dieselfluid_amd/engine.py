@@ -21,6 +21,7 @@ _COMPS = {0: 3, 1: 3, 2: 3, 3: 1, 4: 1, 5: 3, 6: 3}
 KERNEL_IDS = {
     "cell_rank": 0, "scan": 1, "scatter": 2, "density": 3, "force_integrate": 4, "pressure": 5, "viscous": 6,
     "gradient": 7, "external": 8, "update": 9, "pci_predict": 10, "pci_density": 11, "tile_list": 12,
+    "neigh_lists": 13,
 }
 
 
@@ -479,6 +480,17 @@ class SPHEngine:
 
     def timing_reset(self):
         self._ck(self._L.dsl_timing_reset(self._h))
+
+    # library options (include/dslsph.h: DSL_OPT_*)
+    OPTIONS = {"skin": 1, "skin_steps": 2, "skin_rebuilds": 3, "skin_list_overflow": 4, "skin_suspensions": 5}
+
+    def set_option(self, name: str, value: float):
+        self._ck(self._L.dsl_set_option(self._h, self.OPTIONS[name], float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = C.c_double(0.0)
+        self._ck(self._L.dsl_get_option(self._h, self.OPTIONS[name], C.byref(v)))
+        return float(v.value)
 
     def timing(self, kernel: str):
         ms, cnt = C.c_double(0), C.c_int64(0)

@@ -141,7 +141,8 @@ enum {
   DSL_K_PCI_PREDICT = 10,
   DSL_K_PCI_DENSITY = 11,
   DSL_K_TILE_LIST = 12, /* non-empty 4x4x4-cell tiles for the LDS-tiled kernels */
-  DSL_K_COUNT = 13
+  DSL_K_NEIGH_LISTS = 13, /* skin step: wide candidate sweep + neighbour lists (rebuild steps only) */
+  DSL_K_COUNT = 14
 };
 
 typedef struct dsl_handle dsl_handle;
@@ -426,6 +427,31 @@ int dsl_slab_exchange(dsl_handle *h);
 int dsl_slab_replan(dsl_handle *h);
 int dsl_slab_wcsph_step(dsl_handle *h, int nsteps);
 int dsl_slab_pcisph_step(dsl_handle *h, int nsteps);
+
+/* Library options: behaviour that is the product's own and has no counterpart among the reference's parameters.
+ *   DSL_OPT_SKIN (set/get): 0 = off, else a fraction s of h in (0, 0.2]; default 0.1 for DSL_MATH_FAST handles of at
+ *       least two million particles, 0 otherwise.  dsl_wcsph_step (DSL_MATH_FAST, grid
+ *       neighbours, single domain, no boundary particles) then keeps one neighbour LIST per particle, built against the
+ *       cut-off h (1 + s) on cells h (1 + s) wide, and walks it step after step until some particle may have moved
+ *       s h / 2 since the build -- measured on the device, by the integrating kernel, against the build's positions;
+ *       only then does it sort and sweep again.  The sums are the reference's sums over { |x_i - x_j| < h }
+ *       (sph_field.go:155-200,251-269): a listed pair beyond h contributes exactly 0.  The reference itself rebuilds
+ *       its sampler only every 4th CacheIncr (fluid.go:208-215).  DSL_MATH_EXACT rebuilds every step.
+ *       Once the flow outruns the skin (half of the last 16 steps rebuilt -- a rebuild costs about two steps) the
+ *       library suspends it by itself for the next 2048 steps, then tries again; it looks every 32 steps, at step counts
+ *       fixed in advance, so results never depend on timing.
+ *   DSL_OPT_SKIN_STEPS / _REBUILDS / _LIST_OVERFLOW / _SUSPENSIONS (get): skin steps taken, how many of them rebuilt,
+ *       whether some particle's list outgrew 95 entries (it then takes the global-memory sweep: correct, slow), how
+ *       often the library suspended the skin. */
+enum {
+  DSL_OPT_SKIN = 1,
+  DSL_OPT_SKIN_STEPS = 2,
+  DSL_OPT_SKIN_REBUILDS = 3,
+  DSL_OPT_SKIN_LIST_OVERFLOW = 4,
+  DSL_OPT_SKIN_SUSPENSIONS = 5
+};
+int dsl_set_option(dsl_handle *h, int option, double value);
+int dsl_get_option(dsl_handle *h, int option, double *value);
 
 /* global particle ids of the current slots (host order of dsl_upload); default 0..n-1 */
 int dsl_set_ids(dsl_handle *h, const int32_t *ids, size_t count);

@@ -1,0 +1,37 @@
+#!/bin/bash
+# round-4 GPU runs, one parametrised script: tools/gpu_r04.sh <what> [args...]; output under gpurun_out/r4/
+set -o pipefail
+mkdir -p gpurun_out/r4
+what=$1; shift
+case "$what" in
+  skin_tests)   timeout -k 10 900 python -m pytest tests/test_gpu_skin.py -x -q -m gpu "$@" > gpurun_out/r4/skin_tests.log 2>&1; rc=$?; tail -15 gpurun_out/r4/skin_tests.log; exit $rc ;;
+  tests)        timeout -k 10 1100 python -m pytest tests -x -q -m gpu "$@" > gpurun_out/r4/tests.log 2>&1; rc=$?; tail -15 gpurun_out/r4/tests.log; exit $rc ;;
+  bench)        tag=$1; shift; timeout -k 10 900 python bench.py "$@" > gpurun_out/r4/bench_$tag.json 2> gpurun_out/r4/bench_$tag.err; rc=$?; tail -3 gpurun_out/r4/bench_$tag.err; cat gpurun_out/r4/bench_$tag.json; exit $rc ;;
+  prof)         # tools/gpu_r04.sh prof <tag> <kernel-filter> <bench args...>: rocprofv3 kernel stats + PMC passes of one bench command
+    tag=$1; flt=$2; shift 2
+    out=$GRAFT_REPO_ROOT/gpurun_out/r4/prof_$tag; mkdir -p $out
+    export TMPDIR=/tmp; cd /tmp
+    BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 $*"
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats_$tag -- $BENCH > $out/bench.json 2> $out/stats.err || exit 1
+    cp $(find /tmp/prof_stats_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+    python3 - $(find /tmp/prof_stats_$tag -name "*kernel_trace.csv" | head -1) > $out/long_launches.txt <<'PYEOF'
+import csv, sys, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    big = [round(x, 1) for x in v if x > 30.0]
+    print(f"{k}: n={len(v)} total_us={sum(v):.0f} launches>30us: {big[:40]}")
+PYEOF
+    i=0
+    for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" \
+               "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+               "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU_TRANS_F32" \
+               "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE"; do
+      i=$((i+1))
+      rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/prof_pmc_${tag}_$i -- $BENCH > /dev/null 2> $out/pmc$i.err || echo "pmc set $i failed"
+    done
+    python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/prof_pmc_${tag}_1 /tmp/prof_pmc_${tag}_2 /tmp/prof_pmc_${tag}_3 /tmp/prof_pmc_${tag}_4 /tmp/prof_pmc_${tag}_5 --filter "$flt" > $out/pmc.md
+    head -30 $out/kernel_stats.csv; exit 0 ;;
+  *) echo "unknown: $what"; exit 2 ;;
+esac
