@@ -211,12 +211,30 @@ func (c *Comm) Count() (int, error) {
 	return int(n), nil
 }
 
-// NewCommCustom: a communicator over the host's own transport (MPI, sockets, ...) instead of RCCL.  The table's
-// callbacks are C function pointers (exported Go functions via //export, or plain C); the library calls them in
-// exactly the order it would call RCCL (dsl_transport in include/dslsph.h).
-func NewCommCustom(nranks, rank, device int, table *C.dsl_transport) (*Comm, error) {
+// Transport: the host's own transport behind NewCommCustom (dsl_transport in include/dslsph.h).  The callbacks are C
+// function pointers -- exported Go functions via //export, or plain C -- held as unsafe.Pointer so that packages other
+// than this one can fill the table (cgo's C.dsl_transport is private to the package that imports "C").
+type Transport struct {
+	Ctx             unsafe.Pointer
+	GroupStart      unsafe.Pointer // int (*)(void *ctx)
+	GroupEnd        unsafe.Pointer // int (*)(void *ctx)
+	Send            unsafe.Pointer // int (*)(void *ctx, const void *dev_buf, size_t bytes, int peer, void *stream)
+	Recv            unsafe.Pointer // int (*)(void *ctx, void *dev_buf, size_t bytes, int peer, void *stream)
+	AllReduceMaxU32 unsafe.Pointer // int (*)(void *ctx, void *dev_buf, size_t count, void *stream)
+}
+
+// NewCommCustom: a communicator over the host's own transport (MPI, sockets, ...) instead of RCCL.  The library calls
+// the table's callbacks in exactly the order it would call RCCL; the table is copied.
+func NewCommCustom(nranks, rank, device int, t Transport) (*Comm, error) {
+	var table C.dsl_transport
+	table.ctx = t.Ctx
+	*(*unsafe.Pointer)(unsafe.Pointer(&table.group_start)) = t.GroupStart
+	*(*unsafe.Pointer)(unsafe.Pointer(&table.group_end)) = t.GroupEnd
+	*(*unsafe.Pointer)(unsafe.Pointer(&table.send)) = t.Send
+	*(*unsafe.Pointer)(unsafe.Pointer(&table.recv)) = t.Recv
+	*(*unsafe.Pointer)(unsafe.Pointer(&table.all_reduce_max_u32)) = t.AllReduceMaxU32
 	c := &Comm{}
-	if rc := C.dsl_comm_create_custom(C.int(nranks), C.int(rank), C.int(device), table, &c.c); rc != 0 {
+	if rc := C.dsl_comm_create_custom(C.int(nranks), C.int(rank), C.int(device), &table, &c.c); rc != 0 {
 		return nil, errors.New(C.GoString(C.dsl_comm_last_error()))
 	}
 	return c, nil

@@ -17,7 +17,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -115,7 +114,8 @@ struct dsl_handle {
   // their ids at the slots the atomic ranks name, one byte per particle that marks their particles
   unsigned int* unordered = nullptr;
   int *sort_keys = nullptr, *sort_work = nullptr;
-  int* cell_keys = nullptr;  // kCellKeys ids per grid cell: the one-pass in-cell ordering (kernels_grid.hpp); DSL_CELL_KEYS=0: off
+  int* cell_keys = nullptr;  // kCellKeys ids per grid cell: the one-pass in-cell ordering (kernels_grid.hpp); DSL_OPT_CELL_KEYS = 0: nullptr
+  int* cell_keys_alloc = nullptr;
   float* stage = nullptr;
   DevStats* dstats = nullptr;
   int cur_pv = 0, cur_ids = 0, cur_f = 0, cur_pci = 0;
@@ -836,7 +836,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->scratch1);
   (void)hipFree(h->rank);
   (void)hipFree(h->sort_keys);
-  (void)hipFree(h->cell_keys);
+  (void)hipFree(h->cell_keys_alloc);
   (void)hipFree(h->sort_work);
   (void)hipFree(h->unordered);
   (void)hipFree(h->cell_count);
@@ -1036,11 +1036,9 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
     return bail(DSL_ERR_DEVICE);
   }
   h->lsh = params->neigh_mode == DSL_NEIGH_LSH_REF;
-  {
-    bool want_rows = !h->lsh;
-    if (const char* e = std::getenv("DSL_CELL_KEYS")) want_rows = want_rows && std::atoi(e) != 0;
-    if (want_rows && (rc = dev_alloc(h, &h->cell_keys, (size_t)h->ncell_pad * kCellKeys))) return bail(rc);
-  }
+  // (the cells' key rows of the one-pass in-cell ordering: DSL_OPT_CELL_KEYS = 0 leaves them unused)
+  if (!h->lsh && (rc = dev_alloc(h, &h->cell_keys_alloc, (size_t)h->ncell_pad * kCellKeys))) return bail(rc);
+  h->cell_keys = h->cell_keys_alloc;
   if (h->lsh) {
     const int B = params->lsh_buckets;
     h->lsh_cap = params->lsh_bucket_size > kLshSamples ? params->lsh_bucket_size : kLshSamples;
@@ -1054,23 +1052,6 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       h->err = "hipMemsetAsync failed";
       return bail(DSL_ERR_DEVICE);
     }
-  }
-  if (const char* e = std::getenv("DSL_DENSITY_PAIR")) h->density_pair = std::atoi(e) != 0;
-  if (const char* e = std::getenv("DSL_PCI_QTILED")) h->pci_qtiled = std::atoi(e) != 0;
-  if (const char* e = std::getenv("DSL_PCI_QPAIR")) h->pci_qpair = std::atoi(e) != 0;
-  if (const char* e = std::getenv("DSL_PCI_QROWS")) h->pci_qrows = std::atoi(e) != 0;
-  if (const char* e = std::getenv("DSL_PCI_BINNED")) {  // -1 never, 0 automatic, 1 always (dsl_pcisph_set_binning)
-    const int m = std::atoi(e);
-    h->pci_bin_mode = m < 0 ? -1 : (m > 0 ? 1 : 0);
-  }
-  if (const char* e = std::getenv("DSL_PERSISTENT_BLOCKS")) h->max_persistent_blocks = std::atoi(e);
-  // list order: boxes of 8 x 4 x 4 tiles = the 128 entries an XCD works on at a time (kernels_tiled.hpp: TileGrid)
-  if (const char* e = std::getenv("DSL_TILE_BOX")) {  // "bx,by,bz" (A/B runs); "0" = the tile grid's linear order
-    int bx = 0, by = 0, bz = 0;
-    if (std::sscanf(e, "%d,%d,%d", &bx, &by, &bz) < 3 || bx <= 0 || by <= 0 || bz <= 0) bx = by = bz = 0;
-    h->tile_box[0] = bx;
-    h->tile_box[1] = by;
-    h->tile_box[2] = bz;
   }
   if ((rc = set_tile_grid(h))) return bail(rc);
   // (room for the skin step's grid as well: wider cells, but tiles of 3 cell layers in z -- at most 4/3 of these tiles)
@@ -1796,6 +1777,31 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
       h->skin = (float)value;
       h->skin_retry_at = 0;
       return DSL_OK;
+    // the fall-back forms of the kernels (A/B runs, tests: each is product code some configuration or failure path
+    // reaches, tests/test_gpu_variants.py holds every one of them to the default's parity bar)
+    case DSL_OPT_DENSITY_PAIR: h->density_pair = value != 0.0; return DSL_OK;
+    case DSL_OPT_CELL_KEYS:
+      h->cell_keys = value != 0.0 ? h->cell_keys_alloc : nullptr;
+      h->grid_valid = false;
+      return DSL_OK;
+    case DSL_OPT_PERSISTENT_BLOCKS:
+      if (!(value >= 0.0 && value <= 65536.0)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_PERSISTENT_BLOCKS is a workgroup count (0 = no cap)");
+      h->max_persistent_blocks = (int)value;
+      return DSL_OK;
+    case DSL_OPT_TILE_BOX: {  // bx | by << 8 | bz << 16; 0 = the tile grid's linear order
+      const int v = (int)value, bx = v & 255, by = (v >> 8) & 255, bz = (v >> 16) & 255;
+      if (value < 0.0 || value >= 16777216.0 || (v != 0 && (bx == 0 || by == 0 || bz == 0)))
+        return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_TILE_BOX is bx | by << 8 | bz << 16 (all three positive), or 0");
+      h->tile_box[0] = bx;
+      h->tile_box[1] = by;
+      h->tile_box[2] = bz;
+      h->grid_valid = false;
+      h->masks_valid = false;
+      return set_tile_grid(h);
+    }
+    case DSL_OPT_PCI_QTILED: h->pci_qtiled = value != 0.0; return DSL_OK;
+    case DSL_OPT_PCI_QPAIR: h->pci_qpair = value != 0.0; return DSL_OK;
+    case DSL_OPT_PCI_QROWS: h->pci_qrows = value != 0.0; return DSL_OK;
     default:
       return fail(h, DSL_ERR_INVALID, "dsl_set_option: unknown or read-only option");
   }
@@ -1815,6 +1821,13 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_SKIN_REBUILDS: *value = (double)(h->skin_rebuilds_total + s.n_rebuilds); return DSL_OK;
     case DSL_OPT_SKIN_LIST_OVERFLOW: *value = (h->skin_list_overflow || s.list_overflow != 0) ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_SKIN_SUSPENSIONS: *value = (double)h->skin_suspensions; return DSL_OK;
+    case DSL_OPT_DENSITY_PAIR: *value = h->density_pair ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_CELL_KEYS: *value = h->cell_keys != nullptr ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_PERSISTENT_BLOCKS: *value = (double)h->max_persistent_blocks; return DSL_OK;
+    case DSL_OPT_TILE_BOX: *value = (double)(h->tile_box[0] | (h->tile_box[1] << 8) | (h->tile_box[2] << 16)); return DSL_OK;
+    case DSL_OPT_PCI_QTILED: *value = h->pci_qtiled ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_PCI_QPAIR: *value = h->pci_qpair ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_PCI_QROWS: *value = h->pci_qrows ? 1.0 : 0.0; return DSL_OK;
     default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
   }
 }
@@ -1831,6 +1844,7 @@ int dsl_pcisph_begin(dsl_handle* h) {
   if (h->pci_steps != 0) HIP_TRY(h, hipMemsetAsync(h->pci_drift, 0, 512 * sizeof(unsigned int), h->stream));
   h->pci_steps = 0;
   h->pci_binned = false;
+  if (h->drift_pending) HIP_TRY(h, hipEventSynchronize(h->ev_drift));  // (the snapshot copy may still be in flight)
   h->drift_pending = false;
   HIP_TRY(h, hipMemsetAsync(&h->dstats->pci_escaped, 0, sizeof(int), h->stream));
   return DSL_OK;
@@ -2502,12 +2516,6 @@ int dsl_slab_detach(dsl_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   SlabLink* L = h->link;
   if (L->comm_stream) (void)hipStreamSynchronize(L->comm_stream);
-  if (std::getenv("DSL_SLAB_GRAPH_DEBUG"))
-    std::fprintf(stderr, "[dsl] slab link: %lld steps, %lld graph captures; host seconds: launches %.4f, RCCL post %.4f, events/waits %.4f\n",
-                 (long long)L->steps, (long long)L->captures, L->host_seg_s, L->host_post_s, L->host_sync_s);
-  for (auto& per_segment : L->seg)
-    for (SegGraph& g : per_segment)
-      if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (int k = 0; k < 2; ++k) {
     (void)hipFree(L->send[k]);
     (void)hipFree(L->recv[k]);
@@ -2545,11 +2553,6 @@ int dsl_slab_attach(dsl_handle* h, dsl_comm* comm, int lo_rank, int hi_rank, flo
   L->max_full = 2 * cap_full;  // room for the re-plan to grow the messages (the same on every rank)
   L->max_x = 2 * cap_xonly;
   L->overlap = overlap != 0 && (lo_rank >= 0 || hi_rank >= 0);
-  // (measured on MI355X, 2M particles per rank: replaying the step's segments as hipGraphs is 5 % SLOWER than
-  // launching its ~20 kernels one by one -- the host needs 45 us per step for them either way, the GPU 500 us;
-  // profiles/r02_slab_*.  Off unless asked for.)
-  L->use_graphs = false;
-  if (const char* e = std::getenv("DSL_SLAB_GRAPHS")) L->use_graphs = std::atoi(e) != 0;
   L->buf_floats = (size_t)(L->max_full + 1) * kRecordPci + (size_t)L->max_x * kRecordX;  // (13-float records once PCISPH runs)
   for (int k = 0; k < 2; ++k) {
     if (int rc = dev_alloc(h, &L->send[k], L->buf_floats)) return rc;
@@ -2680,136 +2683,50 @@ int dsl_slab_replan(dsl_handle* h) {
   return link_replan(h);
 }
 
-namespace {
-StepState step_state(const dsl_handle* h) {
-  return StepState{h->cur_pv,      h->cur_ids,    h->cur_f,          h->cur_pci,    h->grid_valid,   h->masks_valid,
-                   h->dens_fresh,  h->forces_uniform, h->press_zero, h->split_pending, h->pci_active};
-}
-void set_step_state(dsl_handle* h, const StepState& s) {
-  h->cur_pv = s.cur_pv;
-  h->cur_ids = s.cur_ids;
-  h->cur_f = s.cur_f;
-  h->cur_pci = s.cur_pci;
-  h->grid_valid = s.grid_valid;
-  h->masks_valid = s.masks_valid;
-  h->dens_fresh = s.dens_fresh;
-  h->forces_uniform = s.forces_uniform;
-  h->press_zero = s.press_zero;
-  h->split_pending = s.split_pending;
-}
-// run `body` (kernel launches on h->stream and host bookkeeping, nothing that synchronises): replayed from
-// its hipGraph when nothing it depends on has changed since the capture, captured (and launched) otherwise
-extern "C++" template <class F>
-int run_segment(dsl_handle* h, int which, F&& body) {
-  SlabLink& L = *h->link;
-  if (!L.use_graphs || h->timing != 0) return body();
-  const StepState now = step_state(h);
-  SegGraph& g = L.seg[which][now.cur_ids & 1];
-  if (g.exec && g.before == now && std::memcmp(&g.consts, &h->c, sizeof(DevConsts)) == 0 && g.cap_full == L.cap_full &&
-      g.cap_x == L.cap_x && g.shift_lo == L.shift_from_lo && g.shift_hi == L.shift_from_hi && g.width_full == L.width_full &&
-      g.width == L.width && g.split_width == h->split_width && g.stream == h->stream) {
-    HIP_TRY(h, hipGraphLaunch(g.exec, h->stream));
-    set_step_state(h, g.after);
-    return DSL_OK;
-  }
-  if (g.exec) {
-    (void)hipGraphExecDestroy(g.exec);
-    g.exec = nullptr;
-  }
-  HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-  const int rc = body();
-  hipGraph_t graph = nullptr;
-  const hipError_t e = hipStreamEndCapture(h->stream, &graph);
-  if (rc != DSL_OK || e != hipSuccess) {
-    if (graph) (void)hipGraphDestroy(graph);
-    return rc != DSL_OK ? rc : fail(h, DSL_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-  }
-  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (ei != hipSuccess) {
-    g.exec = nullptr;
-    return fail(h, DSL_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
-  }
-  g.before = now;
-  g.after = step_state(h);
-  g.consts = h->c;
-  g.cap_full = L.cap_full;
-  g.cap_x = L.cap_x;
-  g.shift_lo = L.shift_from_lo;
-  g.shift_hi = L.shift_from_hi;
-  g.width_full = L.width_full;
-  g.width = L.width;
-  g.split_width = h->split_width;
-  g.stream = h->stream;
-  L.captures++;
-  HIP_TRY(h, hipGraphLaunch(g.exec, h->stream));
-  return DSL_OK;
-}
-}  // namespace
-
 int dsl_slab_wcsph_step(dsl_handle* h, int nsteps) {
   CHECK_HANDLE(h);
   if (!h->link) return fail(h, DSL_ERR_INVALID, "dsl_slab_wcsph_step: call dsl_slab_attach first");
   SlabLink& L = *h->link;
   const bool alone = L.lo < 0 && L.hi < 0;
+  // (Round 2 could replay the step's kernel segments as hipGraphs: measured 5 % SLOWER than launching its ~20 kernels one
+  // by one -- the host needs 45 us per step for them either way, the GPU 500 us; profiles/r02_slab_graphs_on_off.txt.
+  // Removed in round 4.)
   for (int s = 0; s < nsteps; ++s) {
     if (!L.ghosts_in)
       if (int rc = link_exchange(h)) return rc;  // first step: migrants + 2h ghosts from both neighbours
     L.ghosts_in = false;
+    // counting sort (drops the previous step's ghosts), densities of owned + ghosts
+    if (int rc = build_grid(h, false)) return rc;
+    if (int rc = density_pass(h)) return rc;
     if (alone || !L.overlap) {
-      // segment 0: counting sort (drops the previous step's ghosts), densities of owned + ghosts, forces and
-      // integration of the owned particles (ghosts are marked for removal), band pack
-      if (int rc = run_segment(h, 0, [&]() -> int {
-            if (int rc = build_grid(h, false)) return rc;
-            if (int rc = density_pass(h)) return rc;
-            if (int rc = force_integrate(h)) return rc;
-            if (alone) return DSL_OK;
-            return slab_pack_on(h, h->stream, L.width_full, L.width, false, L.lo >= 0 ? L.send[0] : nullptr,
-                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x);
-          }))
-        return rc;
+      // forces and integration of the owned particles (ghosts are marked for removal), band pack, transfer, append
+      if (int rc = force_integrate(h)) return rc;
       if (!alone) {
+        if (int rc = slab_pack_on(h, h->stream, L.width_full, L.width, false, L.lo >= 0 ? L.send[0] : nullptr,
+                                  L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x))
+          return rc;
         if (int rc = link_post(h, h->stream)) return rc;
-        if (int rc = run_segment(h, 2, [&]() -> int { return link_append(h); })) return rc;
+        if (int rc = link_append(h)) return rc;
         L.ghosts_in = true;
       }
     } else {
       // band layers first; their pack and the RCCL transfer (side stream) run under the interior launch
-      const auto t0 = std::chrono::steady_clock::now();
-      if (int rc = run_segment(h, 0, [&]() -> int {
-            if (int rc = build_grid(h, false)) return rc;
-            if (int rc = density_pass(h)) return rc;
-            if (int rc = force_integrate(h, 1)) return rc;
-            h->split_pending = true;
-            return slab_pack_on(h, h->stream, L.width_full, h->split_width, true, L.lo >= 0 ? L.send[0] : nullptr,
-                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x);
-          }))
+      if (int rc = force_integrate(h, 1)) return rc;
+      h->split_pending = true;
+      if (int rc = slab_pack_on(h, h->stream, L.width_full, h->split_width, true, L.lo >= 0 ? L.send[0] : nullptr,
+                                L.hi >= 0 ? L.send[1] : nullptr, L.cap_full, L.cap_x))
         return rc;
       // the interior launch is queued BEHIND the pack and BEFORE the transfer is posted: the GPU goes straight from
       // the pack into it, the transfer kernels (side stream, behind the pack's event) join it
-      const auto t1 = std::chrono::steady_clock::now();
       HIP_TRY(h, hipEventRecord(L.ev_pack, h->stream));
-      const auto t4 = std::chrono::steady_clock::now();
-      if (int rc = run_segment(h, 1, [&]() -> int {
-            h->split_pending = false;
-            return force_integrate(h, 2);
-          }))
-        return rc;
-      const auto t5 = std::chrono::steady_clock::now();
+      h->split_pending = false;
+      if (int rc = force_integrate(h, 2)) return rc;
       HIP_TRY(h, hipStreamWaitEvent(L.comm_stream, L.ev_pack, 0));
-      const auto t2 = std::chrono::steady_clock::now();
       if (int rc = link_post(h, L.comm_stream)) return rc;
-      const auto t3 = std::chrono::steady_clock::now();
       HIP_TRY(h, hipEventRecord(L.ev_xfer, L.comm_stream));
       HIP_TRY(h, hipStreamWaitEvent(h->stream, L.ev_xfer, 0));
-      const auto t6 = std::chrono::steady_clock::now();
-      if (int rc = run_segment(h, 2, [&]() -> int { return link_append(h); })) return rc;
-      const auto t7 = std::chrono::steady_clock::now();
+      if (int rc = link_append(h)) return rc;
       L.ghosts_in = true;
-      auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-      L.host_seg_s += sec(t0, t1) + sec(t4, t5) + sec(t6, t7);
-      L.host_post_s += sec(t2, t3);
-      L.host_sync_s += sec(t1, t4) + sec(t5, t2) + sec(t3, t6);
     }
     h->steps++;
     L.steps++;

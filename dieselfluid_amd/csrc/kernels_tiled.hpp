@@ -1282,6 +1282,37 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
     }
     if (have) meta_store(metas[cur ^ 1], tw);
     sync_lds();
+    if (ovf) {
+      // A tile beyond the LDS budget: its targets one per lane, by the target prefix alone, the grid's 27 cells from
+      // global memory.  (Not by pair slots: a tile table packs its in-row cell boundaries into 16 bits -- TileMeta::trow
+      // -- and a tile of more than 65535 particles, which only ever exists as such a tile, would get wrong slots.)
+      if constexpr (!WIDE) {
+        const int ntarg = m.tprefix[kTB * kTB];
+        for (int t = tid; t < ntarg; t += kPBlock) {
+          const int g = tile_target(m, t).g;
+          if (bnd.is(g)) {
+            rho[g] = 0.0f;
+            pterm[g] = __uint_as_float(0x7fc00000u);
+            continue;
+          }
+          const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
+          float a = 0.0f;
+          for_each_grid_candidate(c, cell_start, xi, yi, zi, [&](int j) {
+            if (j == g) return;
+            const float dx = xi - p.x[j], dy = yi - p.y[j], dz = zi - p.z[j];
+            const float r2 = dist2<true>(dx, dy, dz);
+            if (r2 < c.hh) {
+              const float q = __builtin_fmaf(-r2, c.inv_hh, 1.0f);
+              a = __builtin_fmaf(c.mass * c.A, q * q, a);
+            }
+          });
+          rho[g] = a;
+          const float pr = tait_eos<true>(c, a, c.eos_d0_grad);
+          pterm[g] = a > 0.0f ? dsl_div<true>(pr, a * a) : 0.0f;
+        }
+      }
+      continue;
+    }
     const int nslots = m.pprefix[kTB * kTB];
     for_each_target<SHARE, kPBlock>(nslots, tid, tid, [&](auto shared_c, int u, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;

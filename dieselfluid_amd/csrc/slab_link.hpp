@@ -141,36 +141,9 @@ inline int xfer_all_reduce_max(dsl_handle* h, dsl_comm* c, void* words, size_t c
 
 }  // namespace
 
-// A segment of the slab step between two RCCL calls can be captured once as a hipGraph and replayed
-// (DSL_SLAB_GRAPHS=1).  `before` is everything the captured launches depend on (the kernel arguments are
-// frozen in the graph): replayed only while it still holds, re-captured otherwise.
-struct StepState {
-  int cur_pv, cur_ids, cur_f, cur_pci;
-  bool grid_valid, masks_valid, dens_fresh, forces_uniform, press_zero, split_pending, pci_active;
-  bool operator==(const StepState& o) const {
-    return cur_pv == o.cur_pv && cur_ids == o.cur_ids && cur_f == o.cur_f && cur_pci == o.cur_pci &&
-           grid_valid == o.grid_valid && masks_valid == o.masks_valid && dens_fresh == o.dens_fresh &&
-           forces_uniform == o.forces_uniform && press_zero == o.press_zero && split_pending == o.split_pending &&
-           pci_active == o.pci_active;
-  }
-};
-struct SegGraph {
-  hipGraphExec_t exec = nullptr;
-  StepState before{}, after{};
-  dsl::DevConsts consts{};
-  int cap_full = -1, cap_x = -1;
-  float shift_lo = 0.f, shift_hi = 0.f, width_full = 0.f, width = 0.f, split_width = 0.f;
-  hipStream_t stream = nullptr;
-};
-constexpr int kSegments = 3;
-
 // The slab's link to its neighbours (dsl_slab_attach): communicator, neighbour ranks, message
 // buffers, the side stream the transfer runs on.
 struct SlabLink {
-  SegGraph seg[kSegments][2];  // [segment][parity of the id map]
-  bool use_graphs = false;     // DSL_SLAB_GRAPHS=1 turns the replay on
-  int64_t captures = 0;
-  double host_seg_s = 0.0, host_post_s = 0.0, host_sync_s = 0.0;  // DSL_SLAB_GRAPH_DEBUG: where the host's time goes
   dsl_comm* comm = nullptr;
   int lo = -1, hi = -1;  // neighbour ranks; -1 = domain end
   float width_full = 0.f, width = 0.f;

@@ -88,7 +88,8 @@ struct DevStats {
   int reserved0_;
   // slab mode, PCISPH: a DensityF query point (the predictor's position, which the reference never re-synchronises)
   // lies more than h beyond a slab plane, i.e. outside what the 2h ghost band covers: its sum is missing neighbours
-  // that live on another rank, and the run no longer equals the single-domain run (dsl_slab_status[1], bit 1)
+  // that live on another rank, and the run no longer equals the single-domain run.  Read with
+  // dsl_pcisph_get_binning(h, .., .., &escaped) (blocking); the slab step drivers do not look at it themselves
   int pci_escaped;
 };
 

@@ -256,8 +256,11 @@ int dsl_pcisph_error_word(dsl_handle *h, uint32_t *dev_word, int store);
  * query: DSL_MATH_EXACT results do not change by a bit).  mode 0 (default): switch when 0.2 % of the queries have left
  * their particle's 4x4x4-cell tile -- looked at every 4 steps through an asynchronous copy of the device's
  * counters that the next look reads (no stall; the decision trails the drift by 4 to 8 steps), a one-way switch until
- * the next dsl_pcisph_begin; 1: always; -1: never.  Environment DSL_PCI_BINNED presets the mode at dsl_create.  (While
- * the handle's stream is being captured into a graph of the host's the automatic look is skipped: set the mode.)
+ * the next dsl_pcisph_begin; 1: always; -1: never.  (While the handle's stream is being captured into a graph of the
+ * host's the automatic look is skipped: set the mode.)  In slab mode every rank latches from ITS OWN counters: in
+ * DSL_MATH_FAST the binned and un-binned sweeps sum in different orders, so a multi-rank FAST run's last bits depend on
+ * the decomposition -- set the mode explicitly (the same on every rank) where that matters; DSL_MATH_EXACT does not care.
+ * The slab step drivers do not look at `escaped` themselves: a host that runs PCISPH across slabs polls it.
  * dsl_pcisph_get_binning: the mode; whether the next correction iteration sorts its queries; and, slab mode (blocking
  * if asked for), whether a query point of an owned particle has drifted more than h beyond a slab plane since
  * dsl_pcisph_begin, i.e. out of what the 2h ghost band covers: from then on this rank's predicted densities -- the
@@ -448,7 +451,17 @@ enum {
   DSL_OPT_SKIN_STEPS = 2,
   DSL_OPT_SKIN_REBUILDS = 3,
   DSL_OPT_SKIN_LIST_OVERFLOW = 4,
-  DSL_OPT_SKIN_SUSPENSIONS = 5
+  DSL_OPT_SKIN_SUSPENSIONS = 5,
+  /* the kernels' fall-back forms (A/B runs and tests; the defaults are the product).  Each is product code that some
+   * configuration or failure path reaches, and tests/test_gpu_variants.py holds each to the default's parity bar. */
+  DSL_OPT_DENSITY_PAIR = 16,      /* 1: FAST density sweep with two targets per lane (default); 0: one lane per target */
+  DSL_OPT_CELL_KEYS = 17,         /* 1: in-cell ordering from per-cell key rows in the scatter pass itself; 0: two passes */
+  DSL_OPT_TILE_BOX = 18,          /* tile-list enumeration boxes bx | by << 8 | bz << 16 (default 8,4,4); 0: linear order */
+  DSL_OPT_PERSISTENT_BLOCKS = 19, /* cap on the persistent grids' workgroups (tests: few workgroups walk many tiles); 0: none */
+  DSL_OPT_PCI_QTILED = 20,        /* binned DensityF: 1 LDS sweep over query tiles (default), 0 global-memory sweep */
+  DSL_OPT_PCI_QPAIR = 21,         /* ... two queries of one cell per lane (default 1) */
+  DSL_OPT_PCI_QROWS = 22          /* ... per-cell query rows instead of a sorted array (default 1; 512 B per GRID CELL,
+                                     allocated when the binned form is first used: 33 GB for the 64M scene's box) */
 };
 int dsl_set_option(dsl_handle *h, int option, double value);
 int dsl_get_option(dsl_handle *h, int option, double *value);

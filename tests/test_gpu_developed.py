@@ -175,11 +175,11 @@ def test_full_size_pcisph_properties(n3, extra, steps):
 
 
 @pytest.mark.parametrize("method", ["wcsph", "pcisph"])
-def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method, monkeypatch):
+def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method):
     """The persistent tile kernels hand a workgroup one tile after another (double-buffered LDS image, rotating tile
     tables: kernels_tiled.hpp).  A scene of a few hundred tiles gives every workgroup ONE tile, so that hand-over is
     never exercised by the other tests -- round 3 shipped a barrier without its LDS drain there and only a 10000-step
-    16M soak noticed.  Here the grid is capped at 8 workgroups (DSL_PERSISTENT_BLOCKS), 60+ tiles each, and the run
+    16M soak noticed.  Here the grid is capped at 8 workgroups (DSL_OPT_PERSISTENT_BLOCKS), 60+ tiles each, and the run
     must give the same BITS as the uncapped engine: FAST arithmetic does not depend on which workgroup sweeps a tile."""
     from dieselfluid_amd import SPHEngine, scenes
     n3 = 64
@@ -190,11 +190,8 @@ def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method, monk
         p.delta = 1.0e-7
     res = []
     for cap in (0, 8):
-        if cap:
-            monkeypatch.setenv("DSL_PERSISTENT_BLOCKS", str(cap))
-        else:
-            monkeypatch.delenv("DSL_PERSISTENT_BLOCKS", raising=False)
         eng = SPHEngine(p, device=0)
+        eng.set_option("persistent_blocks", cap)
         eng.upload("positions", pos)
         eng.reset_forces()
         if method == "pcisph":

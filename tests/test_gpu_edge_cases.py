@@ -128,14 +128,14 @@ def _probe_sets(x, lo, hi, h):
     return inside, near
 
 
-def test_full_size_16m_properties():
-    """BASELINE full size (n3 = 252, 16,003,008 particles), FAST math: checked through
+@pytest.mark.parametrize("n3", [100, 252])
+def test_full_size_16m_properties(n3):
+    """BASELINE full sizes -- configs[1]'s 1,000,000 particles (n3 = 100) and the bench's 16,003,008 (n3 = 252) --, FAST math: checked through
     size-independent properties -- the slot map stays a permutation, cell_start is a valid prefix
     table of the sorted cells, and for every particle inside a probe box the density AND the result of
     the fused force+integrate kernel (new position and velocity) equal a brute-force float64
     evaluation of the reference formulas on the downloaded state (helpers.brute_force_step_f64)."""
     from dieselfluid_amd import SPHEngine, scenes
-    n3 = 252
     p, pos = scenes.dambreak_scene(n3, math_mode=FAST)
     n = n3 ** 3
     eng = SPHEngine(p)
@@ -193,8 +193,36 @@ def test_full_size_16m_properties():
     assert np.abs(dv_got - dv_ora).max() < helpers.fast_velocity_tolerance(p, 1)  # (measured: 0.13 of the model bound)
     # Update resets every force and pressure after a step (fluid.go:192-193)
     assert st.steps == 3 and eng.stats().steps == 3
+    # (c) the SKIN step (DSL_OPT_SKIN: neighbour lists against h (1 + s), kernels_skin.hpp) at full size.  One step from
+    # the state just checked -- list build + walk -- against the float64 brute force of that state, at (a)'s tolerances;
+    eng.set_option("skin", 0.1)
+    xa, va = x1, v1
+    inside_k, near_k = _probe_sets(xa, lo, lo + 5 * h, h)
+    _, wx, wv = helpers.brute_force_step_f64(p, xa, va, inside_k, near_k)
+    s0, r0 = eng.get_option("skin_steps"), eng.get_option("skin_rebuilds")
     eng.wcsph_step(1)
-    assert eng.stats().steps == 4
+    assert (eng.get_option("skin_steps"), eng.get_option("skin_rebuilds")) == (s0 + 1, r0 + 1)
+    xb, vb = eng.download("positions"), eng.download("velocities")
+    dxw, dxg = wx - xa[inside_k].astype(np.float64), xb[inside_k].astype(np.float64) - xa[inside_k].astype(np.float64)
+    assert np.abs(dxg - dxw).max() < 1e-3 * np.abs(dxw).max() + 2e-7 * np.abs(wx).max()
+    dvw, dvg = wv - va[inside_k].astype(np.float64), vb[inside_k].astype(np.float64) - va[inside_k].astype(np.float64)
+    assert np.abs(dvg - dvw).max() < 1e-3 * np.abs(dvw).max()
+    # then four more -- one build, three steps that walk the same lists -- against a twin that sorts and sweeps every
+    # step, at the FAST tolerances of tests/test_gpu_parity.py
+    twin = SPHEngine(p)
+    twin.set_option("skin", 0.0)
+    twin.upload("positions", xb)
+    twin.upload("velocities", vb)
+    twin.reset_forces()
+    twin.wcsph_step(4)
+    eng.wcsph_step(4)
+    assert (eng.get_option("skin_steps"), eng.get_option("skin_rebuilds")) == (s0 + 5, r0 + 2)
+    assert twin.get_option("skin_steps") == 0
+    xs, vs, xt, vt = eng.download("positions"), eng.download("velocities"), twin.download("positions"), twin.download("velocities")
+    twin.close()
+    assert helpers.rel_err(xs, xt) < 2e-6
+    assert np.abs(vs.astype(np.float64) - vt).max() < 2 * helpers.fast_velocity_tolerance(p, 4)
+    assert eng.stats().steps == 8
 
 
 def test_shared_short_passes_match_the_oracle():
@@ -256,3 +284,32 @@ def test_set_params_refreshes_derived_state(math_mode):
         fa, fb = gradient_forces(late), gradient_forces(fresh)
         assert np.array_equal(fa, fb), field
         late.close(); fresh.close()
+
+
+def test_a_tile_of_more_than_65535_particles():
+    """ADVICE r03: a tile's table packs its in-row cell boundaries into 16 bits (TileMeta::trow).  A tile that holds more
+    particles than that -- here: 42^3 = 74,088 particles whose grid box is ONE tile, everything beyond it clamped into
+    its outermost cells -- is beyond the LDS budget anyway and takes the global-memory sweep; its targets are then
+    walked by the 32-bit target prefix alone.  Densities against a float64 KD-tree evaluation of sph_field.go:155-172."""
+    from scipy.spatial import cKDTree
+    from dieselfluid_amd import SPHEngine, scenes
+    n3 = 42
+    p, pos = scenes.dambreak_scene(n3, math_mode=FAST)
+    for a in range(3):  # a 4 x 4 x 4-cell grid in the block's corner: 1 tile
+        p.grid_min[a] = 0.0
+        p.grid_max[a] = 4.0 * p.h
+    eng = SPHEngine(p)
+    eng.upload("positions", pos)
+    eng.density_all()
+    assert eng.stats().grid_cells == 64
+    rho = eng.download("densities")
+    eng.close()
+    h, m = float(p.h), float(p.mass)
+    A = 315.0 / (64.0 * 3.141592653589 * h ** 3)
+    x = pos.astype(np.float64)
+    tree = cKDTree(x)
+    pairs = tree.query_pairs(h, output_type="ndarray")
+    d2 = ((x[pairs[:, 0]] - x[pairs[:, 1]]) ** 2).sum(axis=1)
+    w = m * A * (1.0 - d2 / (h * h)) ** 2
+    want = np.bincount(pairs[:, 0], w, n3 ** 3) + np.bincount(pairs[:, 1], w, n3 ** 3)
+    assert helpers.rel_err(rho, want) < 2e-5

@@ -98,8 +98,8 @@ def test_fast_run_does_not_depend_on_call_grouping(mode):
     assert res[0][4] == (mode >= 0)  # by step 36 more than 0.2 % of the queries have left their tile
 
 
-@pytest.mark.parametrize("variant", ["", "DSL_PCI_QROWS=0", "DSL_PCI_QPAIR=0", "DSL_PCI_QTILED=0"])
-def test_binned_density_matches_a_float64_brute_force_after_the_drift(variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["", "pci_qrows=0", "pci_qpair=0", "pci_qtiled=0"])
+def test_binned_density_matches_a_float64_brute_force_after_the_drift(variant):
     """FAST, 64^3 particles, 60 steps (median drift ~ 1/3 h, every fifth query in another tile): the pressure accumulator
     after the first correction iteration of the next step is (rho* - rho0) delta with rho* a float64 brute-force DensityF
     at the downloaded predicted positions -- for queries INSIDE the fluid, at its surface and outside it.
@@ -107,11 +107,11 @@ def test_binned_density_matches_a_float64_brute_force_after_the_drift(variant, m
     allocation failure of the rows selects), one query per lane, the global-memory sweep."""
     from dieselfluid_amd import SPHEngine
     from scipy.spatial import cKDTree
-    if variant:
-        k, v = variant.split("=")
-        monkeypatch.setenv(k, v)
     p, pos = _scene(64, FAST)
     eng = SPHEngine(p, device=0)
+    if variant:  # (library options, include/dslsph.h: DSL_OPT_PCI_*)
+        k, v = variant.split("=")
+        eng.set_option(k, float(v))
     eng.upload("positions", pos)
     eng.reset_forces()
     eng.pcisph_begin()

@@ -205,7 +205,7 @@ def _pci_params(p, extra):
         p.st_kappa = 25.0 * p.h * p.h
 
 
-def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False, steps=None):
+def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False, steps=None, binned=0):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -218,6 +218,7 @@ def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False, step
                               params_hook=lambda p: _pci_params(p, extra),
                               vel_fn=lambda ids, pos: 0.5 * _vel_fn(ids, pos, axis=2))
     assert drv.engine.eng.slab_record_floats() == 13
+    drv.engine_core.pcisph_set_binning(1 if binned else 0)
     drv.pcisph_step(STEPS if steps is None else steps)
     res = drv.gather_state(n3 ** 3)
     st = drv.engine.status()
@@ -237,7 +238,7 @@ def _pci_worker(rank, world, port, math_mode, n3, extra, out, native=False, step
     dist.destroy_process_group()
 
 
-def _pci_single(n3, math_mode, extra, shuffle=False):
+def _pci_single(n3, math_mode, extra, shuffle=False, binned=0):
     from dieselfluid_amd import SPHEngine, scenes
     p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
     _pci_params(p, extra)
@@ -251,6 +252,7 @@ def _pci_single(n3, math_mode, extra, shuffle=False):
     eng.upload("velocities", vel[perm])
     eng.reset_forces()
     eng.pcisph_begin()
+    eng.pcisph_set_binning(1 if binned else 0)
     eng.pcisph_step(STEPS)
     inv = np.argsort(perm)
     st = eng.stats()
@@ -262,10 +264,9 @@ def _pci_single(n3, math_mode, extra, shuffle=False):
                                                              (0, 3, 24, True, 1), (1, 3, 24, True, 1)])
 def test_pcisph_slabs_match_single_engine(tmp_path, monkeypatch, math_mode, world, n3, extra, binned):
     """binned = 1: every engine (the ranks' and the single one) sorts DensityF's query points into cells of their own
-    (DSL_PCI_BINNED=1: dsl_pcisph_set_binning) -- ghosts are no queries there either"""
-    monkeypatch.setenv("DSL_PCI_BINNED", str(binned))
+    (dsl_pcisph_set_binning(1)) -- ghosts are no queries there either"""
     out = str(tmp_path / "slab_pci.npz")
-    mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out), nprocs=world, join=True)
+    mp.spawn(_pci_worker, args=(world, _free_port(), math_mode, n3, extra, out, False, None, binned), nprocs=world, join=True)
     z = np.load(out)
     info = z["info"]
     assert np.all(z["seen"] == 1)
@@ -273,7 +274,7 @@ def test_pcisph_slabs_match_single_engine(tmp_path, monkeypatch, math_mode, worl
     assert np.all(info[:, 1] == 0)                          # no message / capacity overflow
     assert len(set(info[:, 2].tolist())) == 1               # every rank ran the same number of iterations
     assert np.allclose(info[:, 3], info[0, 3], rtol=0, atol=0)  # ... on the same, global, error
-    pos, vel, iters, err = _pci_single(n3, math_mode, extra)
+    pos, vel, iters, err = _pci_single(n3, math_mode, extra, binned=binned)
     assert int(info[0, 2]) == iters
     if math_mode == 0:
         # EXACT: the same bits as the single engine (error word included) and as the single-domain oracle
@@ -283,7 +284,7 @@ def test_pcisph_slabs_match_single_engine(tmp_path, monkeypatch, math_mode, worl
         _assert_identical("the single-domain oracle", z["pos"], z["vel"], opos, ovel)
         return
     assert abs(info[0, 3] - err) <= 1e-3 * max(err, 1e-6)
-    pos_s, vel_s, _, _ = _pci_single(n3, math_mode, extra, shuffle=True)
+    pos_s, vel_s, _, _ = _pci_single(n3, math_mode, extra, shuffle=True, binned=binned)
     tol_x = max(4e-6, 5.0 * helpers.rel_err(pos_s, pos))
     tol_v = max(1e-4, 5.0 * helpers.rel_err(vel_s, vel))
     ex, ev = helpers.rel_err(z["pos"], pos), helpers.rel_err(z["vel"], vel)
@@ -399,13 +400,10 @@ def test_native_step_driver_matches_the_python_protocol():
         dist.init_process_group("gloo", rank=0, world_size=1)
     try:
         res = {}
-        # "native": the step's kernels are launched one by one (the default); "native_graphs": captured once
-        # and replayed as hipGraphs (DSL_SLAB_GRAPHS=1, read by dsl_slab_attach)
-        for kind in ("python", "native", "native_graphs"):
+        for kind in ("python", "native"):
             for overlap in (False, True):
                 drv = PeriodicDriver.dambreak(64, math_mode=1, device=0, rank=1, world=4, overlap=overlap, native=False)
                 drv.comm_dev, drv.use_nccl = torch.device("cpu"), False
-                os.environ["DSL_SLAB_GRAPHS"] = "1" if kind == "native_graphs" else "0"
                 if kind != "python":
                     comm = Comm(1, 0, 0)
                     drv.attach_native(comm, 0, 0)
@@ -420,13 +418,12 @@ def test_native_step_driver_matches_the_python_protocol():
                 res[(kind, overlap)] = (ids[o], pos[o], vel[o])
                 drv.engine_core.close()
         for overlap in (False, True):
-            for kind in ("native", "native_graphs"):
+            for kind in ("native",):
                 a, b = res[("python", overlap)], res[(kind, overlap)]
                 assert np.array_equal(a[0], b[0]) and a[0].shape[0] > 60000
                 assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
                 assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     finally:
-        os.environ.pop("DSL_SLAB_GRAPHS", None)
         if created:
             dist.destroy_process_group()
 

@@ -302,3 +302,74 @@ def test_two_particles_closed_form():
     assert np.allclose(s.velocities()[:, 0], [v0, 0.2 - v0], rtol=2e-6)
     assert np.allclose(s.positions()[:, 0], [v0 * 0.01, 0.5 + (0.2 - v0) * 0.01], rtol=2e-6, atol=1e-9)
     assert np.allclose(s.forces(), [[0.0, -9.81, 0.0]] * 2) and np.all(s.pressures() == 0)
+
+
+def test_three_particles_one_pcisph_step_worked_by_hand():
+    """Three collinear particles, one PCISPH step restated from the reference's formulas alone (float64, this function):
+    DensityAll (sph_field.go:155-172), then the correction loop of pcisph_darwin.go:52-98 -- predict (:57-73), DensityF at
+    the predicted position, which STARTS at W0 and meets the particle itself as well (sph_field.go:137-152: rho* = 2 W0 +
+    rho), the pressure accumulator (density_error * delta, :76-92), GradientPressureForce with P/rho^2 of the CURRENT
+    densities, ADDED to the force (fluid.go:164-172, sph_field.go:175-200: the force on i points TOWARDS j) -- the SIGNED
+    max error of :95-98 (all errors negative: 0 <= 1 %, the loop ends after its first iteration; errors of +30 %: it runs
+    all of them), then Update (fluid.go:175-197).  Velocities start at zero, so ViscousAll adds nothing."""
+    PI = 3.141592653589
+    A, B = 315.0 / (64.0 * PI), -45.0 / PI  # h = 1
+    x0 = np.array([[0.0, 0.0, 0.0], [0.4, 0.0, 0.0], [0.9, 0.0, 0.0]])
+    dt, m, d0 = 0.01, 1.0, 1.0
+
+    def F(r):
+        return np.where(r < 1.0, A * (1.0 - r * r) ** 2, 0.0)
+
+    def by_hand(ref_density, iters_max, delta):
+        x, v = x0.copy(), np.zeros_like(x0)
+        r = np.abs(x[:, None, 0] - x[None, :, 0])
+        rho = np.array([sum(m * F(r[i, j]) for j in range(3) if j != i) for i in range(3)])
+        force = np.zeros_like(x0)
+        ppos, pvel = x.copy(), v.copy()
+        press = np.zeros(3)
+        P = (2.15 / 7.16) * ((np.maximum(rho, d0) / d0) ** 7.16 - 1.0)
+        iters, err = 0, 0.0
+        for it in range(iters_max):
+            iters = it + 1
+            err = 0.0
+            pvel = pvel + (force / m) * dt
+            ppos = ppos + pvel * dt
+            for i in range(3):
+                calc = A + sum(m * F(np.linalg.norm(ppos[i] - x[j])) for j in range(3))  # W0 + every sample, itself included
+                e = calc - ref_density
+                press[i] += e * delta
+                err = max(err, e / ref_density)
+            for i in range(3):
+                g = np.zeros(3)
+                for j in range(3):
+                    if j == i:
+                        continue
+                    d = x[j] - x[i]
+                    rr = np.linalg.norm(d)
+                    if rr < 1.0:
+                        g += (d / rr) * (-(B * (1.0 - rr) ** 2)) * (P[i] / rho[i] ** 2 + P[j] / rho[j] ** 2)
+                force[i] += g * rho[i] * m
+            if err <= 0.01:
+                break
+        v = v + (force / m) * dt
+        x = x + v * dt
+        return x, v, iters, err, rho
+
+    for ref_density, iters_max, want_iters in ((8.0, 5, 1), (2.0, 3, 3)):
+        prm = po.params_reference(4)
+        prm.neigh_mode = po.NEIGH_ALL
+        prm.eos_d0_grad = d0  # (FLUID_DENSITY = 87 would clamp every pressure of this tiny system to 0)
+        prm.d0_override = ref_density
+        prm.pci_max_iters = iters_max
+        s = po.OracleSPH.from_state(prm, x0.astype(np.float32), vel=np.zeros((3, 3), dtype=np.float32),
+                                    force=np.zeros((3, 3), dtype=np.float32))
+        s.delta = 0.5
+        s.pcisph_begin()
+        s.pcisph_step(1)
+        x, v, iters, err, rho = by_hand(ref_density, iters_max, 0.5)
+        assert iters == want_iters and s.pci_iters == iters
+        assert abs(s.pci_error - err) <= 2e-6 * max(abs(err), 1.0)
+        assert err == 0.0 if want_iters == 1 else err > 0.3
+        assert np.allclose(s.velocities(), v, rtol=5e-6, atol=1e-9) and np.allclose(s.positions(), x, rtol=5e-6, atol=1e-9)
+        assert v[0, 0] > 0 and v[2, 0] < 0  # the reference's sign: the outer particles are pulled inwards
+        assert np.allclose(s.forces(), [[0.0, -9.81, 0.0]] * 3) and np.all(s.pressures() == 0)

@@ -8,8 +8,8 @@ from oracle import pyoracle as po
 from dieselfluid_amd import SPHEngine, scenes
 
 def run(pair, x, v, p, steps):
-    os.environ["DSL_DENSITY_PAIR"] = "1" if pair else "0"
     e = SPHEngine(p, device=0)
+    e.set_option("density_pair", 1 if pair else 0)
     e.upload("positions", x); e.upload("velocities", v)
     frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (x.shape[0], 1)); e.upload("forces", frc)
     e.density_all()
@@ -20,8 +20,8 @@ def run(pair, x, v, p, steps):
     return out
 
 p, pos = scenes.dambreak_scene(20, math_mode=1)
-os.environ["DSL_DENSITY_PAIR"] = sys.argv[1] if len(sys.argv) > 1 else "0"  # which kernel makes the snapshot
-e = SPHEngine(p, device=0); e.upload("positions", pos); e.reset_forces(); e.wcsph_step(2500)
+e = SPHEngine(p, device=0); e.set_option("density_pair", int(sys.argv[1]) if len(sys.argv) > 1 else 0)  # which kernel makes the snapshot
+e.upload("positions", pos); e.reset_forces(); e.wcsph_step(2500)
 x, v = e.download("positions"), e.download("velocities"); e.close()
 frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (x.shape[0], 1))
 ora = po.OracleSPH.from_state(helpers.oracle_params(p), x, vel=v, force=frc)
