@@ -390,16 +390,26 @@ def main():
                    "queries_binned": bool(eng.pcisph_binning()[1]),
                    "note": "pci_predict = predict + the queries' counting sort + query-tile tables, pci_density = the sweep; "
                            "per correction iteration"}
-    # HBM bytes per launch from the PMC counters cannot be sampled from inside this process;
-    # they come from the committed rocprofv3 passes of this same command (profiles/traffic.json)
-    # and are only quoted for the configuration they were measured on.
-    traffic = None
+    # HBM bytes per launch and the vector-ALU counters cannot be sampled from inside this process; they come from the
+    # committed rocprofv3 --pmc passes of this same command (profiles/traffic.json, written by tools/make_traffic.py from
+    # the round's final profile) and are only quoted for the configuration and the kernel they were measured on.
+    traffic = valu = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if world == 1 and tj.get("particles") == n_total and args.math == "fast":
+        if world == 1 and tj.get("particles") == n_total and args.math == "fast" and kname in tj:
             traffic = tj[kname]["bytes"]
+            valu = {"insts_per_launch": tj[kname]["insts_valu"], "issue_frac": tj[kname]["valu_issue_frac"],
+                    "busy_frac": tj[kname]["valu_busy_frac"],
+                    "definition": "issue_frac = SQ_INSTS_VALU x 2 / (1024 SIMDs x clocks), busy_frac = SQ_ACTIVE_INST_VALU x 4 / "
+                                  "(1024 SIMDs x clocks); " + tj.get("source", "")}
     except Exception:
-        traffic = None
+        traffic = valu = None
+    hbm_frac = achieved / HBM_PEAK_GBS
+    # the roof that binds: the kernel's real HBM traffic against the peak, or the vector ALUs' busy share
+    real_hbm_frac = (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kms > 0) else None
+    bound = "hbm"
+    if valu is not None and valu["busy_frac"] > max(hbm_frac, real_hbm_frac or 0.0):
+        bound = "valu"
 
     if rank == 0:
         value = n_total * args.steps / dt / 1e6
@@ -428,13 +438,16 @@ def main():
                 "parallelism": "single GPU" if world == 1 else f"{world} spatial slabs + 2h halo",
             },
             "roofline": {
-                "bound": "hbm",
+                "bound": bound,
                 "kernel": kname,
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                "traffic_ratio": round(traffic / (n_local * kbytes), 3) if traffic else None,
+                "traffic_frac_of_peak": round(real_hbm_frac, 4) if real_hbm_frac else None,
+                "valu": valu,
                 "avg_ms": round(kms, 4),
                 "bytes_per_particle": kbytes,
                 "pass_density_ms": round(ms_d, 4),

@@ -39,7 +39,10 @@ namespace {
 std::string g_create_error;
 }
 
-constexpr float kSkinDefault = 0.1f;             // DSL_OPT_SKIN of a DSL_MATH_FAST handle ...
+// DSL_OPT_SKIN of a DSL_MATH_FAST handle ...  (0.08: measured best of 0.06 .. 0.10 on the 16M lattice -- 9234 / 9387 /
+// 9288 M particle-steps/s, profiles/r04 -- and a tile of 4 x 4 x 3 such cells stays a fifth below the LDS image's kTCap
+// records where 0.10 sits at its edge: at 0.11 the lattice's fullest tiles no longer fit and the step takes 3.4 ms)
+constexpr float kSkinDefault = 0.08f;
 constexpr int kSkinDefaultParticles = 2000000;  // ... of at least this many particles
 
 struct dsl_handle {
@@ -1620,6 +1623,7 @@ int skin_enter(dsl_handle* h) {
   init.force = 1;
   init.budget = 0.5f * h->skin * h->c.h * (1.0f - 1.0e-3f);
   init.dt = h->c.dt;
+  init.n_live = h->n;
   HIP_TRY(h, hipMemcpyAsync(h->skin_state, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // (`init` lives on this stack frame; entering is rare)
   h->skin_live = true;
@@ -1717,7 +1721,7 @@ int skin_step(dsl_handle* h) {
   h->forces_uniform = true;
   h->press_zero = true;
   h->skin_live_steps += 1;
-  if (h->skin_live_steps % kSkinLook == 0) {
+  if (h->skin_live_steps % kSkinLook == 0 || h->skin_live_steps == 2) {  // (2: the first rebuild's tile statistics are in)
     int give_up = 0;
     HIP_TRY(h, hipMemcpyAsync(&give_up, &st->give_up, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -48,9 +48,13 @@ __global__ void k_skin_decide(SkinState* st) {
   const float d = __builtin_sqrtf(__uint_as_float(st->disp2_bits)) * (1.0f + 1.0e-6f);
   const bool rb = st->force != 0 || !(d <= st->budget);
   st->rebuild = rb ? 1 : 0;
+  // (more than one particle in 64 without a list -- wide cells crowd the tiles' LDS images -- and the global-memory
+  // sweep they fall back to costs more than the lists save: the plain step, whose cells are h wide, is the faster one)
+  if (st->unlisted * 64 > st->n_live) st->give_up = 1;
   if (rb) {
     st->ids_sel ^= 1;
     st->n_rebuilds += 1;
+    st->unlisted = 0;
   }
   st->disp = d;
   st->force = 0;
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg
     if (have) table_word = tile_meta_request(desc, di);
     const int ntarg = m.tprefix[kTB * kTB];
     const unsigned int pad = pad_entry(m);
+    if (m.overflow != 0 && tid == 0) atomicAdd(&st->unlisted, ntarg);
     for_each_target<true, kLBlock>(ntarg, tid, tid, [&](auto shared_c, int t, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;
       if (SHARED && sub != 0) return;  // (a short pass's list is built by the first lane of its group)

@@ -109,7 +109,9 @@ struct SkinState {
   float dt;
   unsigned int history;  // bit k: the step k steps ago rebuilt
   int give_up;      // half of the last 16 steps rebuilt: the flow outruns the skin, the lists no longer pay (host: suspend)
-  int pad_[4];
+  int unlisted;     // targets of the last rebuild that got no list (tiles beyond the LDS budget): they take the global-memory sweep
+  int n_live;       // particles
+  int pad_[2];
 };
 // the gate every kernel of the rebuild chain takes (st == nullptr: no gate, the kernel always runs)
 struct SkinGate {

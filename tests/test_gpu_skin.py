@@ -113,11 +113,27 @@ def test_the_library_suspends_a_skin_the_flow_outruns():
     a.close(); b.close()
 
 
+def test_a_skin_whose_cells_crowd_the_lds_image_is_suspended():
+    """s = 0.2 on the jittered lattice: 4 x 4 x 3 cells of 2.4 dx stage 14 x 14 x 12 = 2352 records and more, more than a
+    tile's LDS image holds -- such tiles get no lists and fall back to the global-memory sweep (correct, several times
+    slower).  The library notices at its first look (step 2) and goes back to the plain step; results to the FAST
+    tolerance of an engine that never had a skin."""
+    n3 = 40
+    p, pos, frc = _scene(n3)
+    a = _engine(p, pos, 0.2)
+    b = _engine(p, pos, 0.0)
+    a.wcsph_step(6); b.wcsph_step(6)
+    assert a.get_option("skin_suspensions") == 1 and a.get_option("skin_steps") == 2
+    assert helpers.rel_err(a.download("positions"), b.download("positions")) < 2e-6
+    assert helpers.rel_err(a.download("densities"), b.download("densities")) < 2e-5
+    a.close(); b.close()
+
+
 def test_skin_default_follows_the_size_and_the_math_mode():
-    """DSL_OPT_SKIN defaults to 0.1 for DSL_MATH_FAST handles of two million particles and more (where a step outweighs
+    """DSL_OPT_SKIN defaults to 0.08 for DSL_MATH_FAST handles of two million particles and more (where a step outweighs
     the gated launches), to 0 below that and in DSL_MATH_EXACT."""
     from dieselfluid_amd import SPHEngine, scenes
-    for n3, mode, want in ((16, 1, 0.0), (128, 1, 0.1), (128, 0, 0.0)):
+    for n3, mode, want in ((16, 1, 0.0), (128, 1, 0.08), (128, 0, 0.0)):
         p, _ = scenes.dambreak_scene(n3, math_mode=mode, positions=False)
         eng = SPHEngine(p, device=0)
         assert abs(eng.get_option("skin") - want) < 1e-7, (n3, mode)

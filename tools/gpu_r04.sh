@@ -32,6 +32,7 @@ PYEOF
       rocprofv3 --kernel-trace --output-format csv --pmc $set -d /tmp/prof_pmc_${tag}_$i -- $BENCH > /dev/null 2> $out/pmc$i.err || echo "pmc set $i failed"
     done
     python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/prof_pmc_${tag}_1 /tmp/prof_pmc_${tag}_2 /tmp/prof_pmc_${tag}_3 /tmp/prof_pmc_${tag}_4 /tmp/prof_pmc_${tag}_5 --filter "$flt" > $out/pmc.md
+    python3 $GRAFT_REPO_ROOT/tools/make_traffic.py $out/pmc.md $out/traffic.json --particles 16003008 --source "profiles/r04_${tag}_pmc.md: rocprofv3 --pmc passes of: bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 $*" > /dev/null
     head -30 $out/kernel_stats.csv; exit 0 ;;
   *) echo "unknown: $what"; exit 2 ;;
 esac
