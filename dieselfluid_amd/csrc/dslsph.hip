@@ -135,6 +135,7 @@ struct dsl_handle {
   bool density_pair = true;  // FAST density with two targets per lane (DSL_DENSITY_PAIR=0: the lane-per-target kernel)
   int max_persistent_blocks = 0;  // DSL_PERSISTENT_BLOCKS (tests)
   int64_t steps = 0;
+  size_t dev_bytes = 0;  // device memory this handle has allocated (DSL_OPT_DEVICE_BYTES)
   // the skin step (kernels_skin.hpp; DSL_OPT_SKIN): neighbour lists against h (1 + skin), walked until some particle may
   // have moved skin * h / 2.  skin_live: the device's SkinState is the authority on which slot -> particle map is current
   // and the grid's cells are h (1 + skin) wide -- every other entry point settles that first (skin_settle).
@@ -339,7 +340,19 @@ int dev_alloc(dsl_handle* h, T** p, size_t count) {
   // unaligned staging quads read past a row nor a plane that is only written for some particles.  Once per handle.
   e = hipMemsetAsync(*p, 0, count * sizeof(T) + 64, h->stream);
   if (e != hipSuccess) return fail(h, DSL_ERR_DEVICE, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+  h->dev_bytes += count * sizeof(T) + 64;
   return DSL_OK;
+}
+
+// Two side arrays cost memory per GRID CELL, not per particle: the cells' key rows of the one-pass in-cell ordering (128 B
+// per cell) and the PCISPH query rows (512 B per cell).  In the dam-break box (8 x the fluid's volume) that is 128 / 512 B
+// per particle; a tall or sparse domain multiplies it.  Each is therefore only allocated within a budget -- the larger of
+// 4 GiB and 64 B per particle slot, or dsl_params.reserved[0] MiB if that is set -- and the kernels fall back to the forms
+// that need none (two-pass ordering; the queries' sorted array), which every parity test also runs.
+bool side_array_fits(const dsl_handle* h, size_t bytes) {
+  size_t budget = std::max((size_t)4 << 30, (size_t)64 * (size_t)h->cap);
+  if (h->prm.reserved[0] > 0) budget = (size_t)h->prm.reserved[0] << 20;
+  return bytes <= budget;
 }
 
 hipEvent_t get_event(dsl_handle* h) {
@@ -916,8 +929,9 @@ int alloc_query_bins(dsl_handle* h) {
     if (!h->qtiles && (rc = dev_alloc(h, &h->qtiles, (size_t)h->tg.ntiles))) return rc;
     if (!h->n_qtiles && (rc = dev_alloc(h, &h->n_qtiles, (size_t)8))) return rc;
     if (!h->qtile_desc && (rc = dev_alloc(h, &h->qtile_desc, (size_t)std::min(h->tg.ntiles, h->cap) * kMetaInts))) return rc;
+    if (h->pci_qrows && h->pci_qpair && h->pci_qtiled && !h->qrows && !side_array_fits(h, (size_t)h->ncell * kQueryRow * sizeof(float4)))
+      h->pci_qrows = false;  // (512 bytes per grid cell: 2.1 GB for the 4M scene's box, 33 GB for the 64M scene's)
     if (h->pci_qrows && h->pci_qpair && h->pci_qtiled && !h->qrows) {
-      // 512 bytes per grid cell (2.1 GB for the 4M scene's 4.1M cells, 33 GB for the 64M scene's -- of 288), touched where queries are
       if (dev_alloc(h, &h->qrows, (size_t)h->ncell * kQueryRow) != DSL_OK) {
         h->qrows = nullptr;
         h->pci_qrows = false;
@@ -1040,7 +1054,9 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   }
   h->lsh = params->neigh_mode == DSL_NEIGH_LSH_REF;
   // (the cells' key rows of the one-pass in-cell ordering: DSL_OPT_CELL_KEYS = 0 leaves them unused)
-  if (!h->lsh && (rc = dev_alloc(h, &h->cell_keys_alloc, (size_t)h->ncell_pad * kCellKeys))) return bail(rc);
+  if (!h->lsh && side_array_fits(h, (size_t)h->ncell_pad * kCellKeys * sizeof(int)) &&
+      (rc = dev_alloc(h, &h->cell_keys_alloc, (size_t)h->ncell_pad * kCellKeys)))
+    return bail(rc);
   h->cell_keys = h->cell_keys_alloc;
   if (h->lsh) {
     const int B = params->lsh_buckets;
@@ -1825,6 +1841,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_SKIN_REBUILDS: *value = (double)(h->skin_rebuilds_total + s.n_rebuilds); return DSL_OK;
     case DSL_OPT_SKIN_LIST_OVERFLOW: *value = (h->skin_list_overflow || s.list_overflow != 0) ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_SKIN_SUSPENSIONS: *value = (double)h->skin_suspensions; return DSL_OK;
+    case DSL_OPT_DEVICE_BYTES: *value = (double)h->dev_bytes; return DSL_OK;
     case DSL_OPT_DENSITY_PAIR: *value = h->density_pair ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_CELL_KEYS: *value = h->cell_keys != nullptr ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PERSISTENT_BLOCKS: *value = (double)h->max_persistent_blocks; return DSL_OK;

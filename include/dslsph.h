@@ -111,6 +111,11 @@ typedef struct dsl_params {
    * (and, in DSL_MATH_EXACT, equal to the reference's sums taken cell by cell).  1: keep the order the
    * counting sort's atomics produce (saves the ordering pass of the scatter; last-bit differences between runs). */
   int32_t sort_unordered;
+  /* reserved[0]: budget, in MiB, for each of the two side arrays that cost memory per GRID CELL rather than per particle
+   * (the cells' key rows of the one-pass in-cell ordering: 128 B per cell; the PCISPH query rows: 512 B per cell); 0 = the
+   * larger of 4 GiB and 64 B per particle slot.  An array beyond its budget is not allocated and the kernels take the
+   * forms that need none (two-pass ordering, the queries' sorted array): same results, a few per cent slower.
+   * reserved[1..3]: 0. */
   int32_t reserved[4];
 } dsl_params;
 
@@ -453,6 +458,7 @@ enum {
   DSL_OPT_SKIN_REBUILDS = 3,
   DSL_OPT_SKIN_LIST_OVERFLOW = 4,
   DSL_OPT_SKIN_SUSPENSIONS = 5,
+  DSL_OPT_DEVICE_BYTES = 6,       /* (get) device memory this handle has allocated so far */
   /* the kernels' fall-back forms (A/B runs and tests; the defaults are the product).  Each is product code that some
    * configuration or failure path reaches, and tests/test_gpu_variants.py holds each to the default's parity bar. */
   DSL_OPT_DENSITY_PAIR = 16,      /* 1: FAST density sweep with two targets per lane (default); 0: one lane per target */

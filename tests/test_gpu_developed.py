@@ -133,7 +133,16 @@ def test_full_size_pcisph_properties(n3, extra, steps):
     del pos
     eng.reset_forces()
     eng.pcisph_begin()
+    if n3 == 400:
+        # the binned iteration's per-cell query rows cost 512 B per GRID CELL -- 33 GB for this scene's
+        # box.  Side arrays that scale with the box are only allocated within a budget (dsl_params.reserved[0]; default the
+        # larger of 4 GiB and 64 B per particle): here the queries take the sorted-array form and the cells' key rows the
+        # two-pass ordering, and the whole handle stays where the particles put it
+        eng.pcisph_set_binning(1)
     eng.pcisph_step(steps)
+    if n3 == 400:
+        assert eng.get_option("pci_qrows") == 0 and eng.get_option("cell_keys") == 0
+        assert eng.get_option("device_bytes") < 24e9, eng.get_option("device_bytes")  # (was 19 + 8.6 + 33 GB)
     st = eng.stats()
     assert st.pci_iters == 4 and st.steps == steps
     assert np.isfinite(st.pci_max_error) and st.pci_max_error > 0

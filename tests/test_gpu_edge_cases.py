@@ -313,3 +313,48 @@ def test_a_tile_of_more_than_65535_particles():
     w = m * A * (1.0 - d2 / (h * h)) ** 2
     want = np.bincount(pairs[:, 0], w, n3 ** 3) + np.bincount(pairs[:, 1], w, n3 ** 3)
     assert helpers.rel_err(rho, want) < 2e-5
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_a_box_eight_times_taller_and_no_budget_for_side_arrays(math_mode):
+    """side arrays that cost memory per GRID CELL (the cells' key rows, the PCISPH query rows) must not
+    decide how tall a domain may be.  The 16^3 dam-break in a box -- and a grid -- 8 x taller, with a 1 MiB budget for each
+    such array (dsl_params.reserved[0]): neither is allocated, the sort orders its cells in two passes, the binned PCISPH
+    iteration keeps its queries in the sorted array -- and the results are the oracle's (EXACT: bit for bit)."""
+    from dieselfluid_amd import SPHEngine, scenes
+    n3 = 16
+    res = {}
+    for budget in (0, 1):
+        p, pos = scenes.dambreak_scene(n3, math_mode=math_mode)
+        p.box_max[1] *= 8.0
+        p.grid_max[1] = p.box_max[1] + p.h
+        p.reserved[0] = budget
+        p.pci_max_iters = 3
+        p.eos_w = p.eos_w / 3
+        p.delta = 1.0e-7
+        frc = np.tile(np.array(p.force_reset[:], dtype=np.float32), (n3 ** 3, 1))
+        eng = SPHEngine(p)
+        assert eng.get_option("cell_keys") == (0 if budget else 1)
+        eng.upload("positions", pos)
+        eng.upload("forces", frc)
+        eng.wcsph_step(6)
+        eng.pcisph_begin()
+        eng.pcisph_set_binning(1)
+        eng.pcisph_step(3)
+        if math_mode == 1:  # (the rows belong to the FAST sweep; EXACT keeps the sorted array whatever the budget)
+            assert eng.get_option("pci_qrows") == (0 if budget else 1)
+        res[budget] = (eng.download("positions"), eng.download("velocities"), eng.get_option("device_bytes"))
+        if budget:
+            ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, force=frc)
+            ora.wcsph_step(6)
+            ora.pcisph_begin()
+            ora.pcisph_step(3)
+            if math_mode == 0:
+                assert np.array_equal(res[1][0].view(np.uint32), ora.positions().view(np.uint32))
+                assert np.array_equal(res[1][1].view(np.uint32), ora.velocities().view(np.uint32))
+            else:
+                assert helpers.rel_err(res[1][0], ora.positions()) < 2e-6
+        eng.close()
+    assert res[1][2] < res[0][2]  # the side arrays are really not there
+    if math_mode == 0:
+        assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
