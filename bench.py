@@ -254,6 +254,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     skin1 = (engines[0].get_option("skin_steps"), engines[0].get_option("skin_rebuilds")) if world == 1 else (0, 0)
+    skin_fields = (engines[0].get_option("skin_fields_own"), engines[0].get_option("skin_fields_padded")) if world == 1 else (0, 0)
     if world > 1:
         dog.arm(limit, "per-kernel timing segment and the closing reductions")
     hot = {k: engines[0].timing(k) for k in ("density", "force_integrate", "pci_density")}
@@ -473,6 +474,9 @@ def main():
             "skin": {"s": eng.get_option("skin"), "steps_in_timed_region": int(skin1[0] - skin0[0]),
                      "rebuilds_in_timed_region": int(skin1[1] - skin0[1]),
                      "list_overflow": int(eng.get_option("skin_list_overflow")),
+                     # list fields per particle at the last rebuild: what the particles need, and what the walks visit
+                     # once every wave's lists are padded to its longest
+                     "fields_per_particle": round(skin_fields[0] / n_total, 2), "fields_walked_per_particle": round(skin_fields[1] / n_total, 2),
                      "suspensions": int(eng.get_option("skin_suspensions"))} if world == 1 else None,
             "n_live_rank0": n_live,
             "n_ranks_seen_by_rccl": ranks_seen,

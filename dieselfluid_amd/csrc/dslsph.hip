@@ -43,7 +43,7 @@ std::string g_create_error;
 // 9288 M particle-steps/s, profiles/r04 -- and a tile of 4 x 4 x 3 such cells stays a fifth below the LDS image's kTCap
 // records where 0.10 sits at its edge: at 0.11 the lattice's fullest tiles no longer fit and the step takes 3.4 ms)
 constexpr float kSkinDefault = 0.08f;
-constexpr int kSkinDefaultParticles = 2000000;  // ... of at least this many particles
+constexpr int kSkinDefaultParticles = 200000;  // ... of at least this many particles (measured: +24 % at 262k, +21 % at 1M, +15 % at 2M, +19 % at 16M)
 
 struct dsl_handle {
   int device = 0;
@@ -1106,7 +1106,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
   h->forces_uniform = false;  // uploaded / zero forces are honoured until the first Update
   h->press_zero = true;
   // the skin step is the default where it pays: DSL_MATH_FAST, enough particles for a step to outweigh the ~40 us of
-  // gated launches it adds (measured break-even near a million; dsl_set_option(DSL_OPT_SKIN) overrides)
+  // gated launches it adds (dsl_set_option(DSL_OPT_SKIN) overrides)
   if (params->math_mode == DSL_MATH_FAST && h->n >= kSkinDefaultParticles) h->skin = kSkinDefault;
   *out = h;
   return DSL_OK;
@@ -1701,9 +1701,6 @@ int skin_step(dsl_handle* h) {
   const double reach = 1.0 + (double)h->skin;
   const float wide_thr = (float)(1.0 - reach * reach * 1.0004 - 1.0e-4);
   rc = timed(h, DSL_K_NEIGH_LISTS, [&] {
-    hipLaunchKernelGGL((k_density_pair<false, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
-                       h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pZ, h->rho, h->pterm, h->nmask,
-                       h->cap, wide_thr, gate);
     hipLaunchKernelGGL((k_density_pair<true, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
                        h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pZ, h->rho, h->pterm, h->nmask,
                        h->cap, wide_thr, gate);
@@ -1831,7 +1828,8 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
   CHECK_HANDLE_ONLY(h);
   if (!value) return fail(h, DSL_ERR_INVALID, "dsl_get_option: null output");
   SkinState s{};
-  if (h->skin_live && (option == DSL_OPT_SKIN_STEPS || option == DSL_OPT_SKIN_REBUILDS || option == DSL_OPT_SKIN_LIST_OVERFLOW)) {
+  if (h->skin_live && (option == DSL_OPT_SKIN_STEPS || option == DSL_OPT_SKIN_REBUILDS || option == DSL_OPT_SKIN_LIST_OVERFLOW ||
+                       option == DSL_OPT_SKIN_FIELDS_OWN || option == DSL_OPT_SKIN_FIELDS_PADDED)) {
     HIP_TRY(h, hipMemcpyAsync(&s, h->skin_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
@@ -1842,6 +1840,8 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_SKIN_LIST_OVERFLOW: *value = (h->skin_list_overflow || s.list_overflow != 0) ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_SKIN_SUSPENSIONS: *value = (double)h->skin_suspensions; return DSL_OK;
     case DSL_OPT_DEVICE_BYTES: *value = (double)h->dev_bytes; return DSL_OK;
+    case DSL_OPT_SKIN_FIELDS_OWN: *value = (double)s.fields_own; return DSL_OK;
+    case DSL_OPT_SKIN_FIELDS_PADDED: *value = (double)s.fields_padded; return DSL_OK;
     case DSL_OPT_DENSITY_PAIR: *value = h->density_pair ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_CELL_KEYS: *value = h->cell_keys != nullptr ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PERSISTENT_BLOCKS: *value = (double)h->max_persistent_blocks; return DSL_OK;

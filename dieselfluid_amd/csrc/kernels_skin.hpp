@@ -55,6 +55,7 @@ __global__ void k_skin_decide(SkinState* st) {
     st->ids_sel ^= 1;
     st->n_rebuilds += 1;
     st->unlisted = 0;
+    st->fields_own = st->fields_padded = 0u;
   }
   st->disp = d;
   st->force = 0;
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg
   // pass, 1 KB per wave and store.  Longer lists (more than 63 entries: rare) store the rest directly.
   constexpr int kLStaged = 8;
   __shared__ uint4 held[kLStaged][kLBlock];
+  __shared__ unsigned int tile_fields[2];
   const int tid = threadIdx.x;
+  if (tid < 2) tile_fields[tid] = 0u;
   TileFeed feed(desc_of, *n_tiles);
   int di = 0;
   bool have = feed.pop(di);
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg
       const bool fits = masks && n <= kLMaxChunks * kLEntries;
       if (masks && !fits) st->list_overflow = 1;  // (benign race: every writer stores 1)
       int fields = fits ? n : 0;
+      const int own_fields = fields;
       if constexpr (!SHARED) {  // the wave's longest list (ballots count the lanes that are here: a pass's last wave may be short)
         int wmax = 0;
 #pragma unroll
@@ -187,6 +191,9 @@ __global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg
         }
         fields = wmax;
       }
+      // statistics of the build (DSL_OPT_SKIN_FIELDS_*): summed in LDS, one pair of global atomics per tile
+      atomicAdd(&tile_fields[0], (unsigned int)own_fields);
+      atomicAdd(&tile_fields[1], (unsigned int)(fits ? fields : 0));
       const int nch = (fields + kLEntries - 1) / kLEntries;  // (full pass: the same for the whole wave)
       if (fits)
         while (n < nch * kLEntries) push(pad);  // the far-away record up to the end of the wave's last chunk
@@ -199,6 +206,12 @@ __global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg
       if (!fits) lists[g] = make_uint4(kLGlobal, 0u, 0u, 0u);
     });
     if (have) tile_meta_store(metas[cur ^ 1], table_word);
+    sync_lds();
+    if (tid == 0) {
+      atomicAdd(&st->fields_own, tile_fields[0]);
+      atomicAdd(&st->fields_padded, tile_fields[1]);
+      tile_fields[0] = tile_fields[1] = 0u;
+    }
   }
 }
 

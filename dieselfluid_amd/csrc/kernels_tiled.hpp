@@ -1221,7 +1221,9 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
   __shared__ float4 A[kTCap];
   const int tid = threadIdx.x;
   if (gate.closed()) return;
-  if (c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
+  // (WIDE: the skin step launches the pass-sharing instantiation alone -- its tiles of 4 x 4 x 3 wide cells hold a few
+  // targets more or less than a block -- and saves a launch that would only find out it is not wanted)
+  if (!WIDE && c.slab_axis < 0 && share_wanted(n_tiles) != SHARE) return;
   auto load4 = [&](int g, float4* o) {
     o[0] = load4u(p.x + g);
     o[1] = load4u(p.y + g);

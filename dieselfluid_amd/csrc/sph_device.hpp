@@ -111,7 +111,8 @@ struct SkinState {
   int give_up;      // half of the last 16 steps rebuilt: the flow outruns the skin, the lists no longer pay (host: suspend)
   int unlisted;     // targets of the last rebuild that got no list (tiles beyond the LDS budget): they take the global-memory sweep
   int n_live;       // particles
-  int pad_[2];
+  // of the last rebuild: list fields the targets need, and fields they hold once padded to their wave's longest list
+  unsigned int fields_own, fields_padded;
 };
 // the gate every kernel of the rebuild chain takes (st == nullptr: no gate, the kernel always runs)
 struct SkinGate {

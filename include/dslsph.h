@@ -459,6 +459,8 @@ enum {
   DSL_OPT_SKIN_LIST_OVERFLOW = 4,
   DSL_OPT_SKIN_SUSPENSIONS = 5,
   DSL_OPT_DEVICE_BYTES = 6,       /* (get) device memory this handle has allocated so far */
+  DSL_OPT_SKIN_FIELDS_OWN = 7,    /* (get, while skin steps are live) list fields the particles needed at the last rebuild ... */
+  DSL_OPT_SKIN_FIELDS_PADDED = 8, /* ... and the fields their lists hold, padded to the longest list of each wave */
   /* the kernels' fall-back forms (A/B runs and tests; the defaults are the product).  Each is product code that some
    * configuration or failure path reaches, and tests/test_gpu_variants.py holds each to the default's parity bar. */
   DSL_OPT_DENSITY_PAIR = 16,      /* 1: FAST density sweep with two targets per lane (default); 0: one lane per target */
