@@ -405,6 +405,14 @@ def main():
                                   "(1024 SIMDs x clocks); " + tj.get("source", "")}
     except Exception:
         traffic = valu = None
+    # the density + force PASS in real traffic: both kernels' counter bytes over both kernels' time
+    pass_traffic_frac = None
+    try:
+        kd, kf = ("k_density_list", "k_force_list") if kname.endswith("_list") else ("k_density", "k_force_integrate")
+        if traffic is not None and kd in tj and kf in tj and (ms_d + ms_f) > 0:
+            pass_traffic_frac = (tj[kd]["bytes"] + tj[kf]["bytes"]) / ((ms_d + ms_f) * 1e-3) / 1e9 / HBM_PEAK_GBS
+    except Exception:
+        pass_traffic_frac = None
     hbm_frac = achieved / HBM_PEAK_GBS
     # the roof that binds: the kernel's real HBM traffic against the peak, or the vector ALUs' busy share
     real_hbm_frac = (traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kms > 0) else None
@@ -455,6 +463,8 @@ def main():
                 "pass_force_ms": round(ms_f, 4),
                 "pass_frac_68B": round(n_local * 68 / ((ms_d + ms_f) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if (ms_d + ms_f) > 0 else None,
+                # the same pass in the bytes the counters saw (lists, halo re-staging included): how busy HBM really is
+                "pass_traffic_frac_of_peak": round(pass_traffic_frac, 4) if pass_traffic_frac else None,
             },
             "kernels_ms": kernels_ms,
             "slab_overflow": overflow,

@@ -1599,7 +1599,7 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // the skin step (kernels_skin.hpp): neighbour lists that live for several steps
 // ---------------------------------------------------------------------------------------
-// Every kSkinLook skin steps the host reads one word of the device state: has the flow outrun the skin (half of the last
+// Every kSkinLook skin steps the host reads one word of the device state: has the flow outrun the skin (five of the last
 // 16 steps rebuilt)?  Then the lists cost more than they save and the step goes back to sorting and sweeping every step
 // for kSkinRetry steps.  Both happen at step counts fixed in advance: results do not depend on timing or on how the
 // steps were grouped into calls.
@@ -1739,7 +1739,8 @@ int skin_step(dsl_handle* h) {
     HIP_TRY(h, hipMemcpyAsync(&give_up, &st->give_up, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (give_up) {
-      h->skin_retry_at = h->steps + 1 + kSkinRetry;
+      // (every suspension in a row doubles the wait, up to 16 x: a flow that has developed rarely calms down again)
+      h->skin_retry_at = h->steps + 1 + ((int64_t)kSkinRetry << std::min(h->skin_suspensions, 4));
       h->skin_suspensions += 1;
       return skin_settle(h);
     }

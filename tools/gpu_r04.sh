@@ -34,5 +34,12 @@ PYEOF
     python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/prof_pmc_${tag}_1 /tmp/prof_pmc_${tag}_2 /tmp/prof_pmc_${tag}_3 /tmp/prof_pmc_${tag}_4 /tmp/prof_pmc_${tag}_5 --filter "$flt" > $out/pmc.md
     python3 $GRAFT_REPO_ROOT/tools/make_traffic.py $out/pmc.md $out/traffic.json --particles 16003008 --source "profiles/r04_${tag}_pmc.md: rocprofv3 --pmc passes of: bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 $*" > /dev/null
     head -30 $out/kernel_stats.csv; exit 0 ;;
+  soak)         # tools/gpu_r04.sh soak <n3> <steps> <runs>: repeated long runs must end in the same bits
+    n3=$1; steps=$2; runs=$3
+    for k in $(seq 1 $runs); do timeout -k 10 400 python tools/soak_developed.py $n3 $steps run$k 2>/dev/null | grep '^{' >> gpurun_out/r4/soak_${n3}.jsonl || exit 1; tail -1 gpurun_out/r4/soak_${n3}.jsonl | cut -c1-400; done
+    python3 -c "
+import json,sys
+r=[json.loads(l) for l in open('gpurun_out/r4/soak_${n3}.jsonl')][-$runs:]
+print('digests', [x['state_sha1'] for x in r]); sys.exit(0 if len({x['state_sha1'] for x in r})==1 and all(x['bad_at'] is None for x in r) else 1)"; exit $? ;;
   *) echo "unknown: $what"; exit 2 ;;
 esac

@@ -1,5 +1,6 @@
 """Soak (GPU box): the 16M bench scene stepped into its developed state, max |v| and the fullest cell printed every
-500 steps; stops at the first non-finite or absurd value.  Looks for rare faults that only a long run meets.
+500 steps; stops at the first non-finite or absurd value.  Looks for rare faults that only a long run meets: repeated runs
+must end in the same bits (state_sha1 of positions + velocities), skin step, suspensions and retries included.
   python tools/soak_developed.py [n3] [steps] [tag]"""
 import json
 import os
@@ -31,7 +32,11 @@ def main():
         if not np.isfinite(st.max_vel) or st.max_vel > 500.0 or st.max_cell_count > 200:
             bad_at = done
             break
+    import hashlib
+    digest = hashlib.sha1(eng.download("positions").tobytes() + eng.download("velocities").tobytes()).hexdigest()[:16]
+    skin = {k: eng.get_option(k) for k in ("skin", "skin_steps", "skin_rebuilds", "skin_suspensions", "skin_list_overflow")}
     out = {"tag": tag, "lib": os.environ.get("DSL_LIB", "default"), "n3": n3, "steps": done, "bad_at": bad_at,
+           "state_sha1": digest, "skin": skin,
            "seconds": round(time.perf_counter() - t0, 1), "last": hist[-3:], "env": {k: v for k, v in os.environ.items() if k.startswith("DSL_")}}
     print(json.dumps(out), flush=True)
     eng.close()
