@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--skin", type=float, default=None,
                     help="N=1 WCSPH, --math fast: DSL_OPT_SKIN, neighbour lists against h (1 + skin) that live until some "
                          "particle has moved skin h / 2 (0 = sort and sweep every step; default: the library's own default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="a library option for A/B runs (include/dslsph.h DSL_OPT_*, e.g. pci_qincr=0); N=1 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange after the whole force pass")
     ap.add_argument("--developed-steps", type=int, default=10000,
@@ -197,6 +199,8 @@ def main():
         eng.reset_forces()
         if args.skin is not None:
             eng.set_option("skin", args.skin)
+        for kv in args.opt:
+            eng.set_option(kv.split("=")[0], float(kv.split("=")[1]))
         del pos
         if args.method == "pcisph":
             eng.pcisph_begin()
@@ -445,6 +449,7 @@ def main():
                  f"uniform-grid neighbours, math={args.math}") + (" + XSPH + cohesion terms" if args.extra_terms else ""),
                 "particles": n_total,
                 "parallelism": "single GPU" if world == 1 else f"{world} spatial slabs + 2h halo",
+                **({"library_options": args.opt} if args.opt else {}),
             },
             "roofline": {
                 "bound": bound,

@@ -104,6 +104,11 @@ struct dsl_handle {
   // scatter pass: kernels_tiled.hpp, tile_setup_load_counts); DSL_PCI_QROWS=0, or an allocation that fails, keeps the array
   float4* qrows = nullptr;
   bool pci_qrows = true;
+  // ... and the rows kept from one correction iteration to the next inside a step (k_pci_predict_bin<.., INCR>): qslot =
+  // every particle's record index; pci_rows_live = this step's rows hold every query (its first iteration filled them)
+  int* qslot = nullptr;
+  bool pci_qincr = true;
+  bool pci_rows_live = false;
   float4* qrec = nullptr;
   unsigned int* pci_drift = nullptr;
   unsigned int* pci_drift_host = nullptr;  // pinned: the snapshot of the counters the next look reads
@@ -866,6 +871,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->n_qtiles);
   (void)hipFree(h->qtile_desc);
   (void)hipFree(h->qrows);
+  (void)hipFree(h->qslot);
   (void)hipFree(h->pci_drift);
   if (h->pci_drift_host) (void)hipHostFree(h->pci_drift_host);
   if (h->ev_drift) (void)hipEventDestroy(h->ev_drift);
@@ -939,6 +945,9 @@ int alloc_query_bins(dsl_handle* h) {
         (void)hipGetLastError();  // (since ROCm 7.0 the last NON-SUCCESS error sticks: the next launch check would report this one)
       }
     }
+    // (a record index is an int: 2^31 / kQueryRow grid cells)
+    if (h->qrows && h->pci_qincr && !h->qslot && (size_t)h->ncell * kQueryRow < ((size_t)1 << 31))
+      if ((rc = dev_alloc(h, &h->qslot, (size_t)h->cap))) return rc;
   }
   return DSL_OK;
 }
@@ -1820,6 +1829,10 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
     case DSL_OPT_PCI_QTILED: h->pci_qtiled = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QPAIR: h->pci_qpair = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: h->pci_qrows = value != 0.0; return DSL_OK;
+    case DSL_OPT_PCI_QINCR:
+      h->pci_qincr = value != 0.0;
+      h->pci_rows_live = false;
+      return DSL_OK;
     default:
       return fail(h, DSL_ERR_INVALID, "dsl_set_option: unknown or read-only option");
   }
@@ -1850,6 +1863,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_PCI_QTILED: *value = h->pci_qtiled ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QPAIR: *value = h->pci_qpair ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: *value = h->pci_qrows ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_PCI_QINCR: *value = h->pci_qincr ? 1.0 : 0.0; return DSL_OK;
     default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
   }
 }
@@ -1922,6 +1936,7 @@ bool pci_extra_terms(const dsl_handle* h) { return h->c.xsph_eps != 0.0f || h->c
 // NN, DensityAll, ViscousAll (pcisph_darwin.go:43-45) and the loop set-up
 int pci_begin_step(dsl_handle* h) {
   const DevConsts& c = h->c;
+  h->pci_rows_live = false;  // (the sort re-numbers the particles: the query rows start afresh)
   if (int rc = pci_drift_check(h)) return rc;
   if (int rc = build_grid(h, false)) return rc;
   if (int rc = density_pass(h)) return rc;        // DensityAll  pcisph_darwin.go:44
@@ -1980,8 +1995,13 @@ int pci_iterate(dsl_handle* h) {
     CSoa3 cG{h->gterm[0], h->gterm[1], h->gterm[2]};
     const bool qtiled = tiled && h->pci_qtiled;
     const bool rows = qtiled && h->pci_qpair && h->pci_qrows && h->qrows != nullptr;
-    if (h->qcount_dirty) HIP_TRY(h, hipMemsetAsync(h->qcount, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
+    // rows kept inside a step: the first iteration fills them (and leaves the counts standing), the later ones move only
+    // the queries that have changed cells
+    const bool keep = rows && h->pci_qincr && h->qslot != nullptr;
+    const bool incr = keep && h->pci_rows_live;
+    if (h->qcount_dirty && !incr) HIP_TRY(h, hipMemsetAsync(h->qcount, 0, sizeof(int) * (size_t)h->ncell_pad, h->stream));
     h->qcount_dirty = true;
+    h->pci_rows_live = false;
     // n_qtiles[0] tile list length, [1] spilled queries: left at zero by k_pci_reset / k_pci_check (a memset node costs
     // 7 us on the device, four per step); only a host that iterates twice without the check in between gets one here
     if (rows && (h->pci_iter_pending || !h->pci_counters_clean)) HIP_TRY(h, hipMemsetAsync(h->n_qtiles, 0, 2 * sizeof(int), h->stream));
@@ -1989,13 +2009,18 @@ int pci_iterate(dsl_handle* h) {
     h->pci_iter_pending = true;
     int rc = timed(h, DSL_K_PCI_PREDICT, [&] {
       if (rows) {
-        hipLaunchKernelGGL((k_pci_predict_bin<false, true, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
-                           h->qcount, nullptr, nullptr, nullptr, h->dcounter + 4, h->build_seq, h->press, h->dstats, h->qrows, kQueryRow,
-                           h->qrec, h->n_qtiles + 1);
+        if (incr)
+          hipLaunchKernelGGL((k_pci_predict_bin<false, true, true, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
+                             h->qcount, nullptr, nullptr, nullptr, h->dcounter + 4, h->build_seq, h->press, h->dstats, h->qrows,
+                             kQueryRow, h->qrec, h->n_qtiles + 1, h->qslot);
+        else
+          hipLaunchKernelGGL((k_pci_predict_bin<false, true, true, true>), g, b, 0, h->stream, c, bnd_of(h), p, pp, pvv, cG, F,
+                             h->qcount, nullptr, nullptr, nullptr, h->dcounter + 4, h->build_seq, h->press, h->dstats, h->qrows,
+                             kQueryRow, h->qrec, h->n_qtiles + 1, keep ? h->qslot : nullptr);
         hipLaunchKernelGGL(k_qtile_list<true>, dim3(grid_for(h->tg.nlist)), dim3(kBlock), 0, h->stream, c, h->tg, h->qcount,
                            h->qtiles, h->n_qtiles, h->dstats);
         hipLaunchKernelGGL(k_tile_desc, dim3(std::min(h->tg.ntiles, 8192)), dim3(kWave), 0, h->stream, c, h->tg,
-                           h->cell_start, nullptr, h->qtiles, h->n_qtiles, h->qtile_desc, h->qcount);
+                           h->cell_start, nullptr, h->qtiles, h->n_qtiles, h->qtile_desc, h->qcount, kTCap, SkinGate{nullptr}, keep);
         return;
       }
       if (tiled)
@@ -2018,7 +2043,8 @@ int pci_iterate(dsl_handle* h) {
     });
     if (rc) return rc;
     HIP_TRY(h, hipGetLastError());
-    h->qcount_dirty = false;  // (the kernels that leave the histogram zeroed are queued)
+    h->qcount_dirty = keep;  // (otherwise the kernels that leave the histogram zeroed are queued)
+    h->pci_rows_live = keep;
     rc = timed(h, DSL_K_PCI_DENSITY, [&] {
       if (rows) {
         hipLaunchKernelGGL(k_pci_density_qpair<true>, dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,

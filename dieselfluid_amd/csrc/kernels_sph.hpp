@@ -639,7 +639,14 @@ __device__ __forceinline__ void pci_drift_add(unsigned int* __restrict__ drift, 
 // of `row_slots` records (qrows), or, when the row is full, behind the spill list (spill, n_spill), which a
 // global-memory sweep finishes; qrank is then unused and n_qtiles is cleared by the host (the spill counter sits
 // next to it and is written by this very launch).
-template <bool GHOSTS, bool ADD_G, bool FAST, bool ROWS = false>
+// ROWS, INCR (the second and later iterations of a step): the rows are KEPT from the previous iteration.  A query point
+// moves a few thousandths of h per iteration, so nearly every query is still in the cell it was in: it overwrites its own
+// record (qslot[i], the record's index, written by the step's first iteration) -- no atomic, where the full form pays ~4M
+// of them with a return value per iteration, 0.16 ms at 4M whatever their scope (tools/atomic_scope.hip).  A query
+// that has changed cells leaves a tombstone (particle -1: the sweep computes it and drops the result) and takes the next
+// free slot of its new cell's row; the counts only ever grow inside a step, and the step's first iteration starts from
+// empty rows again (the sort has re-numbered the particles by then anyway).
+template <bool GHOSTS, bool ADD_G, bool FAST, bool ROWS = false, bool INCR = false>
 __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd, CSoa3 p, Soa3 pp, Soa3 pv, CSoa3 gterm,
                                                             Soa3 frc, int* __restrict__ qcount, int* __restrict__ qrank,
                                                             int* __restrict__ n_qtiles, unsigned int* __restrict__ drift,
@@ -647,7 +654,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
                                                             float* __restrict__ press, DevStats* stats,
                                                             float4* __restrict__ qrows = nullptr,
                                                             int row_slots = 0, float4* __restrict__ spill = nullptr,
-                                                            int* __restrict__ n_spill = nullptr) {
+                                                            int* __restrict__ n_spill = nullptr,
+                                                            int* __restrict__ qslot = nullptr) {
+  static_assert(!INCR || ROWS, "only the query rows persist between iterations");
   if (stats->pci_done) return;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (!ROWS && i == 0 && n_qtiles != nullptr) *n_qtiles = 0;  // the length of this iteration's query-tile list (k_qtile_list)
@@ -703,6 +712,30 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
   // scene (tools/pci_query_spread.py) -- the drift is noisy, not a smooth displacement -- and grouping equal cells across
   // the whole wave (tried) then finds nothing to group.  Those ~4M device-scope atomics with a return value on random
   // words of a 16 MB histogram are ~120 us of this kernel, about what that many random 64-byte accesses cost.
+  if constexpr (INCR) {
+    if (i < live_n(c)) {
+      const int old = qslot[i];
+      if (old >= 0 && old / row_slots == cell) {
+        qrows[old] = rec;
+      } else {
+        if (old >= 0) reinterpret_cast<int*>(qrows)[(size_t)old * 4 + 3] = -1;
+        int now = -1;
+        if (cell >= 0) {
+          const int r = atomicAdd(&qcount[cell], 1);
+          if (r < row_slots) {
+            now = cell * row_slots + r;
+            qrows[now] = rec;
+          } else {
+            spill[atomicAdd(n_spill, 1)] = rec;
+          }
+        }
+        if (now != old) qslot[i] = now;
+      }
+    }
+    if (drift != nullptr) pci_drift_add(drift, left ? 1u : 0u, mine ? 1u : 0u);
+    wave_atomic_max(&stats->pci_cur_err_bits, err_bits);
+    return;
+  }
   const int prev = __shfl_up(cell, 1, kWave);
   const bool head = (lane == 0) || (cell != prev);
   const unsigned long long heads = __ballot(head);
@@ -718,6 +751,9 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
       const int r = base + (lane - head_lane);
       if (r < row_slots) qrows[(size_t)cell * row_slots + r] = rec;
       else spill[atomicAdd(n_spill, 1)] = rec;  // (rare: more queries in one cell than a row holds)
+      if (qslot != nullptr) qslot[i] = r < row_slots ? cell * row_slots + r : -1;
+    } else if (qslot != nullptr && i < live_n(c)) {
+      qslot[i] = -1;
     }
   } else {
     if (i < live_n(c)) qrank[i] = cell >= 0 ? base + (lane - head_lane) : -1;

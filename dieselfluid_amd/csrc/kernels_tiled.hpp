@@ -246,8 +246,9 @@ __device__ __forceinline__ void tile_setup_load(const DevConsts& c, const TileGr
 // row r's four interior cells (the same shape tile_setup_load gives the particles' table) and leaves the counts zero
 // for the next iteration -- every cell with a count belongs to exactly one listed tile.
 constexpr int kQueryRow = 32;
+// (keep: the counts stay -- the rows are carried into the next iteration, k_pci_predict_bin<.., INCR>)
 __device__ __forceinline__ void tile_setup_load_counts(const DevConsts& c, const TileGrid& tg, int tile,
-                                                       int* __restrict__ qcount, TileSetupRegs& r) {
+                                                       int* __restrict__ qcount, TileSetupRegs& r, bool keep) {
   const int tid = threadIdx.x;
 #pragma unroll
   for (int k = 0; k <= kTH; ++k) r.s[k] = 0;
@@ -267,7 +268,7 @@ __device__ __forceinline__ void tile_setup_load_counts(const DevConsts& c, const
 #pragma unroll
     for (int k = 0; k < kTB; ++k) {
       const int x = tx * kTB + k;
-      if (cnt[k] != 0) qcount[row + x] = 0;
+      if (cnt[k] != 0 && !keep) qcount[row + x] = 0;
       r.s[k + 2] = r.s[k + 1] + min(cnt[k], kQueryRow);
     }
     r.s[kTH] = r.s[kTB + 1];
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
                                                      const int* __restrict__ target_start,
                                                      const int* __restrict__ tiles, const int* __restrict__ n_tiles,
                                                      int* __restrict__ desc, int* __restrict__ query_counts = nullptr,
-                                                     int lds_cap = kTCap, SkinGate gate = SkinGate{nullptr}) {
+                                                     int lds_cap = kTCap, SkinGate gate = SkinGate{nullptr},
+                                                     bool keep_counts = false) {
   // (query_counts != nullptr: query rows, see tile_setup_load_counts; target_start is then unused)
   // (lds_cap: staged records the sweeping kernel's LDS image holds -- kTCap, or the skin step's wider image)
   if (gate.closed()) return;
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(kWave) void k_tile_desc(DevConsts c, TileGrid tg, c
     if (two) tile_setup_load(c, tg, tile2, cell_start, r2);
     if (query_counts != nullptr) {
       TileSetupRegs q, q2;
-      tile_setup_load_counts(c, tg, tile, query_counts, q);
-      if (two) tile_setup_load_counts(c, tg, tile2, query_counts, q2);
+      tile_setup_load_counts(c, tg, tile, query_counts, q, keep_counts);
+      if (two) tile_setup_load_counts(c, tg, tile2, query_counts, q2, keep_counts);
       table(item, tile, r, q);
       if (two) table(item2, tile2, r2, q2);
     } else if (queries) {
@@ -2655,6 +2657,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_pci_density_qpair(DevConsts c, T
     }
   };
   auto finish = [&](int g, float density) {  // pressure accumulate + the iteration's error (pcisph_darwin.go:76-92)
+    if (ROWS && g < 0) return;  // (the tombstone of a query that has moved to another cell's row: k_pci_predict_bin<.., INCR>)
     const float density_error = density - c.ref_density;
     const float abs_err = density_error * __builtin_amdgcn_rcpf(c.ref_density);
     press[g] += density_error * c.delta;

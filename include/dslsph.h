@@ -469,8 +469,10 @@ enum {
   DSL_OPT_PERSISTENT_BLOCKS = 19, /* cap on the persistent grids' workgroups (tests: few workgroups walk many tiles); 0: none */
   DSL_OPT_PCI_QTILED = 20,        /* binned DensityF: 1 LDS sweep over query tiles (default), 0 global-memory sweep */
   DSL_OPT_PCI_QPAIR = 21,         /* ... two queries of one cell per lane (default 1) */
-  DSL_OPT_PCI_QROWS = 22          /* ... per-cell query rows instead of a sorted array (default 1; 512 B per GRID CELL,
+  DSL_OPT_PCI_QROWS = 22,         /* ... per-cell query rows instead of a sorted array (default 1; 512 B per GRID CELL,
                                      allocated when the binned form is first used: 33 GB for the 64M scene's box) */
+  DSL_OPT_PCI_QINCR = 23          /* ... the rows kept from one correction iteration of a step to the next: only a query that
+                                     has changed cells is moved (default 1; 0: every iteration fills the rows afresh) */
 };
 int dsl_set_option(dsl_handle *h, int option, double value);
 int dsl_get_option(dsl_handle *h, int option, double *value);

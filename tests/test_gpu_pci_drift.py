@@ -98,13 +98,16 @@ def test_fast_run_does_not_depend_on_call_grouping(mode):
     assert res[0][4] == (mode >= 0)  # by step 36 more than 0.2 % of the queries have left their tile
 
 
-@pytest.mark.parametrize("variant", ["", "pci_qrows=0", "pci_qpair=0", "pci_qtiled=0"])
+@pytest.mark.parametrize("variant", ["", "pci_qincr=0", "pci_qrows=0", "pci_qpair=0", "pci_qtiled=0"])
 def test_binned_density_matches_a_float64_brute_force_after_the_drift(variant):
     """FAST, 64^3 particles, 60 steps (median drift ~ 1/3 h, every fifth query in another tile): the pressure accumulator
-    after the first correction iteration of the next step is (rho* - rho0) delta with rho* a float64 brute-force DensityF
-    at the downloaded predicted positions -- for queries INSIDE the fluid, at its surface and outside it.
-    The variants are the forms the library falls back to: the sorted query array instead of per-cell rows (also what an
-    allocation failure of the rows selects), one query per lane, the global-memory sweep."""
+    after EACH of the next step's four correction iterations is the sum of (rho* - rho0) delta with rho* a float64
+    brute-force DensityF at the predicted positions downloaded after that iteration -- for queries INSIDE the fluid, at its
+    surface and outside it.  From the second iteration on the default form keeps the query rows and moves only the queries
+    that have changed cells (tombstones, late entries: k_pci_predict_bin<.., INCR>).
+    The variants are the forms the library falls back to: rows filled afresh in every iteration, the sorted query array
+    instead of per-cell rows (also what an allocation failure of the rows selects), one query per lane, the global-memory
+    sweep."""
     from dieselfluid_amd import SPHEngine
     from scipy.spatial import cKDTree
     p, pos = _scene(64, FAST)
@@ -118,30 +121,39 @@ def test_binned_density_matches_a_float64_brute_force_after_the_drift(variant):
     eng.pcisph_step(60)
     assert eng.pcisph_binning() == (0, True)
     eng.pcisph_phase(0)
-    eng.pcisph_phase(1)
-    x, xp, press = eng.download("positions"), eng.download("pci_positions"), eng.download("pressures")
-    assert np.isfinite(x).all() and np.isfinite(xp).all() and np.isfinite(press).all()
+    x = eng.download("positions")
+    assert np.isfinite(x).all()
     h, m = float(p.h), float(p.mass)
     A = 315.0 / (64.0 * 3.141592653589 * h ** 3)
     tree = cKDTree(x.astype(np.float64))
     probe = np.random.default_rng(5).choice(x.shape[0], 4000, replace=False)
-    rho = np.empty(probe.shape[0])
-    nn = np.empty(probe.shape[0], dtype=np.int64)
-    for k, g in enumerate(probe):
-        q = xp[g].astype(np.float64)
-        idx = tree.query_ball_point(q, h)
-        d2 = ((x[idx].astype(np.float64) - q) ** 2).sum(axis=1)
-        d2 = d2[d2 < h * h]
-        nn[k] = d2.shape[0]
-        rho[k] = A + m * A * ((1.0 - d2 / (h * h)) ** 2).sum()
-    want = (rho - float(p.ref_density)) * float(p.delta)
-    err = np.abs(press[probe] - want).max()
-    print(f"neighbour counts of the probed queries: min {nn.min()} median {int(np.median(nn))} max {nn.max()}; max error {err:.3e}")
-    assert nn.min() < 8 and nn.max() > 30  # queries outside / at the surface / inside
-    assert err < 4e-7 * np.abs(want).max() + 3e-5 * float(p.ref_density) * float(p.delta)
-    for _ in range(3):
-        eng.pcisph_phase(2); eng.pcisph_phase(1)
-    eng.pcisph_phase(2); eng.pcisph_phase(3)
+    want = np.zeros(probe.shape[0])
+    cells_before = None
+    for it in range(4):
+        eng.pcisph_phase(1)
+        xp, press = eng.download("pci_positions"), eng.download("pressures")
+        assert np.isfinite(xp).all() and np.isfinite(press).all()
+        cells = np.floor((xp.astype(np.float64) - np.array(p.grid_min[:])) / h).astype(np.int64)
+        if cells_before is not None:
+            moved = int((cells != cells_before).any(axis=1).sum())
+            assert moved > 100  # (queries that change cells between two iterations: what the kept rows have to follow)
+        cells_before = cells
+        rho = np.empty(probe.shape[0])
+        nn = np.empty(probe.shape[0], dtype=np.int64)
+        for k, g in enumerate(probe):
+            q = xp[g].astype(np.float64)
+            idx = tree.query_ball_point(q, h)
+            d2 = ((x[idx].astype(np.float64) - q) ** 2).sum(axis=1)
+            d2 = d2[d2 < h * h]
+            nn[k] = d2.shape[0]
+            rho[k] = A + m * A * ((1.0 - d2 / (h * h)) ** 2).sum()
+        want += (rho - float(p.ref_density)) * float(p.delta)
+        err = np.abs(press[probe] - want).max()
+        print(f"iteration {it}: neighbour counts of the probed queries: min {nn.min()} median {int(np.median(nn))} max {nn.max()}; max error {err:.3e}")
+        assert nn.min() < 8 and nn.max() > 30  # queries outside / at the surface / inside
+        assert err < (it + 1) * (4e-7 * np.abs(want).max() + 3e-5 * float(p.ref_density) * float(p.delta))
+        eng.pcisph_phase(2)
+    eng.pcisph_phase(3)
     assert eng.stats().pci_iters == 4
     eng.close()
 

@@ -4,6 +4,7 @@ set -o pipefail
 mkdir -p gpurun_out/r4
 what=$1; shift
 case "$what" in
+  some_tests)   f=$1; shift; timeout -k 10 1100 python -m pytest $f -x -q -m gpu "$@" > gpurun_out/r4/some_tests.log 2>&1; rc=$?; tail -25 gpurun_out/r4/some_tests.log; exit $rc ;;
   skin_tests)   timeout -k 10 900 python -m pytest tests/test_gpu_skin.py -x -q -m gpu "$@" > gpurun_out/r4/skin_tests.log 2>&1; rc=$?; tail -15 gpurun_out/r4/skin_tests.log; exit $rc ;;
   tests)        timeout -k 10 1100 python -m pytest tests -x -q -m gpu "$@" > gpurun_out/r4/tests.log 2>&1; rc=$?; tail -15 gpurun_out/r4/tests.log; exit $rc ;;
   bench)        tag=$1; shift; timeout -k 10 900 python bench.py "$@" > gpurun_out/r4/bench_$tag.json 2> gpurun_out/r4/bench_$tag.err; rc=$?; tail -3 gpurun_out/r4/bench_$tag.err; cat gpurun_out/r4/bench_$tag.json; exit $rc ;;
