@@ -43,6 +43,9 @@ std::string g_create_error;
 // 9288 M particle-steps/s, profiles/r04 -- and a tile of 4 x 4 x 3 such cells stays a fifth below the LDS image's kTCap
 // records where 0.10 sits at its edge: at 0.11 the lattice's fullest tiles no longer fit and the step takes 3.4 ms)
 constexpr float kSkinDefault = 0.08f;
+// the lists are built where the particles will be about half way through the lists' life: the fastest particle may use up
+// this fraction of the displacement budget at the build itself (DSL_OPT_SKIN_PREDICT; 0: built where the particles are)
+constexpr float kSkinPredict = 0.8f;
 constexpr int kSkinDefaultParticles = 200000;  // ... of at least this many particles (measured: +24 % at 262k, +21 % at 1M, +15 % at 2M, +19 % at 16M)
 
 struct dsl_handle {
@@ -157,6 +160,8 @@ struct dsl_handle {
   SkinState* skin_state = nullptr;
   uint4* lists = nullptr;
   float* pvz[6] = {};  // the sort's output set of a skin step (Z)
+  float* pvr[3] = {};  // ... and the build's reference positions x + tau v in the same order (SkinState::tau)
+  float skin_predict = kSkinPredict;  // DSL_OPT_SKIN_PREDICT
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
@@ -523,7 +528,7 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work),
                   want_dest ? h->rank : nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
+    hipLaunchKernelGGL(k_scatter<false>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
     if (ordered)  // (with key rows: the flag-gated fallback for cells of more than kCellKeys particles, a small grid)
       hipLaunchKernelGGL(k_scatter_ordered, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
                          h->stream, c, a, so, p, h->rank, h->cell_start);
@@ -878,6 +883,7 @@ void free_all(dsl_handle* h) {
   (void)hipFree(h->skin_state);
   (void)hipFree(h->lists);
   for (int k = 0; k < 6; ++k) (void)hipFree(h->pvz[k]);
+  for (int k = 0; k < 3; ++k) (void)hipFree(h->pvr[k]);
   (void)hipFree(h->stage);
   (void)hipFree(h->dstats);
   (void)hipFree(h->dcounter);
@@ -1627,6 +1633,8 @@ int skin_alloc(dsl_handle* h) {
   if (!h->lists && (rc = dev_alloc(h, &h->lists, (size_t)kLMaxChunks * h->cap))) return rc;
   for (int k = 0; k < 6; ++k)
     if (!h->pvz[k] && (rc = dev_alloc(h, &h->pvz[k], (size_t)h->cap))) return rc;
+  for (int k = 0; k < 3; ++k)
+    if (!h->pvr[k] && (rc = dev_alloc(h, &h->pvr[k], (size_t)h->cap))) return rc;
   return DSL_OK;
 }
 
@@ -1649,6 +1657,8 @@ int skin_enter(dsl_handle* h) {
   init.budget = 0.5f * h->skin * h->c.h * (1.0f - 1.0e-3f);
   init.dt = h->c.dt;
   init.n_live = h->n;
+  init.predict = h->skin_predict;
+  init.vmax2_bits = 0x7f800000u;  // (unknown until a skin step has integrated: the first build is where the particles are)
   HIP_TRY(h, hipMemcpyAsync(h->skin_state, &init, sizeof(init), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));  // (`init` lives on this stack frame; entering is rare)
   h->skin_live = true;
@@ -1664,14 +1674,18 @@ int skin_step(dsl_handle* h) {
   const int X = h->cur_pv, Y = X ^ 1;
   const CSoa3 pX = cpos(h), vX = cvel(h);
   const CSoa3 pZ{h->pvz[0], h->pvz[1], h->pvz[2]}, vZ{h->pvz[3], h->pvz[4], h->pvz[5]};
+  // the build's REFERENCE positions x + tau v in sorted order (SkinState::tau): what the sort's cells, the candidate
+  // sweep and the lists are built at, and what displacement is measured against
+  const CSoa3 pR{h->pvr[0], h->pvr[1], h->pvr[2]};
+  const Soa3 pRw{h->pvr[0], h->pvr[1], h->pvr[2]};
   const bool ordered = !h->prm.sort_unordered;
   hipLaunchKernelGGL(k_skin_decide, dim3(1), dim3(1), 0, h->stream, st);
   HIP_TRY(h, hipGetLastError());
   // the rebuild chain: launched every step, every kernel returns at once unless this step rebuilds
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
-    hipLaunchKernelGGL(k_cell_rank<false>, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, pX.x, pX.y, pX.z,
+    hipLaunchKernelGGL((k_cell_rank<false, true>), dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, pX.x, pX.y, pX.z,
                        ordered ? h->ids[0] : nullptr, h->rank, h->cell_count, h->unordered, nullptr, nullptr,
-                       ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0, gate, h->ids[1]);
+                       ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0, gate, h->ids[1], vX);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_SCAN, [&] {
@@ -1692,10 +1706,11 @@ int skin_step(dsl_handle* h) {
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work), nullptr,
                   ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate);
+    hipLaunchKernelGGL(k_scatter<true>, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate,
+                       vX, pRw);
     if (ordered)
-      hipLaunchKernelGGL(k_scatter_ordered, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
-                         h->stream, c, a, so, pX, h->rank, h->cell_start, gate);
+      hipLaunchKernelGGL(k_scatter_ordered<true>, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
+                         h->stream, c, a, so, pX, h->rank, h->cell_start, gate, vX, pRw);
   });
   if (rc) return rc;
   rc = timed(h, DSL_K_TILE_LIST, [&] {
@@ -1711,10 +1726,10 @@ int skin_step(dsl_handle* h) {
   const float wide_thr = (float)(1.0 - reach * reach * 1.0004 - 1.0e-4);
   rc = timed(h, DSL_K_NEIGH_LISTS, [&] {
     hipLaunchKernelGGL((k_density_pair<true, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
-                       h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pZ, h->rho, h->pterm, h->nmask,
+                       h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pR, h->rho, h->pterm, h->nmask,
                        h->cap, wide_thr, gate);
     hipLaunchKernelGGL(k_list_build, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
-                       h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pZ, wide_thr);
+                       h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pR, wide_thr);
   });
   if (rc) return rc;
   // the step itself: densities and the fused force + integrate over the lists
@@ -1729,7 +1744,7 @@ int skin_step(dsl_handle* h) {
     dim3 g(persistent_grid(h, 2)), b(kLBlock);
 #define DSL_LAUNCH_FL(GG, VV)                                                                                             \
   hipLaunchKernelGGL((k_force_list<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, h->tile_desc,       \
-                     h->cell_start, st, pX, vX, pZ, vZ, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats)
+                     h->cell_start, st, pX, vX, pZ, vZ, pR, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats)
     if (G && V) DSL_LAUNCH_FL(true, true);
     else if (G) DSL_LAUNCH_FL(true, false);
     else DSL_LAUNCH_FL(false, true);
@@ -1804,6 +1819,10 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
       h->skin = (float)value;
       h->skin_retry_at = 0;
       return DSL_OK;
+    case DSL_OPT_SKIN_PREDICT:
+      if (!(value >= 0.0 && value <= 0.95)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_SKIN_PREDICT is a fraction of the displacement budget in [0, 0.95]");
+      h->skin_predict = (float)value;
+      return DSL_OK;
     // the fall-back forms of the kernels (A/B runs, tests: each is product code some configuration or failure path
     // reaches, tests/test_gpu_variants.py holds every one of them to the default's parity bar)
     case DSL_OPT_DENSITY_PAIR: h->density_pair = value != 0.0; return DSL_OK;
@@ -1843,7 +1862,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
   if (!value) return fail(h, DSL_ERR_INVALID, "dsl_get_option: null output");
   SkinState s{};
   if (h->skin_live && (option == DSL_OPT_SKIN_STEPS || option == DSL_OPT_SKIN_REBUILDS || option == DSL_OPT_SKIN_LIST_OVERFLOW ||
-                       option == DSL_OPT_SKIN_FIELDS_OWN || option == DSL_OPT_SKIN_FIELDS_PADDED)) {
+                       option == DSL_OPT_SKIN_FIELDS_OWN || option == DSL_OPT_SKIN_FIELDS_PADDED || option == DSL_OPT_SKIN_TAU_STEPS)) {
     HIP_TRY(h, hipMemcpyAsync(&s, h->skin_state, sizeof(s), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
@@ -1856,6 +1875,8 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_DEVICE_BYTES: *value = (double)h->dev_bytes; return DSL_OK;
     case DSL_OPT_SKIN_FIELDS_OWN: *value = (double)s.fields_own; return DSL_OK;
     case DSL_OPT_SKIN_FIELDS_PADDED: *value = (double)s.fields_padded; return DSL_OK;
+    case DSL_OPT_SKIN_PREDICT: *value = h->skin_predict; return DSL_OK;
+    case DSL_OPT_SKIN_TAU_STEPS: *value = s.dt > 0.0f ? (double)s.tau / (double)s.dt : 0.0; return DSL_OK;
     case DSL_OPT_DENSITY_PAIR: *value = h->density_pair ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_CELL_KEYS: *value = h->cell_keys != nullptr ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PERSISTENT_BLOCKS: *value = (double)h->max_persistent_blocks; return DSL_OK;

@@ -39,13 +39,16 @@ __device__ __forceinline__ int sort_cell(const DevConsts& c, float x, float y, f
   return cell_of(c, x, y, z);
 }
 
+// a skin build's reference coordinate (one fma, the same in every kernel that needs the particle's cell)
+__device__ __forceinline__ float skin_ref(float x, float v, float tau) { return __builtin_fmaf(tau, v, x); }
+
 // `unordered` is a bitmap over the cells: a set bit marks a cell whose slot order the scatter has to
 // establish (see k_scatter): it received more than one run, or a run that was not ascending in
 // particle id.  A lattice at rest has neither (a cell's particles are one run, in the order the
 // previous step left them), so the ordering costs next to nothing there.
 // (OFF_GRID is a template parameter: as a run-time test of the pointer the check cost the WCSPH build 0.022 of this
 // kernel's 0.122 ms at 16M although it never ran)
-template <bool OFF_GRID>
+template <bool OFF_GRID, bool REF = false>
 __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* __restrict__ px,
                                                       const float* __restrict__ py,
                                                       const float* __restrict__ pz, const int* __restrict__ ids,
@@ -54,8 +57,10 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
                                                       int* __restrict__ n_tiles, int* __restrict__ cell_keys,
                                                       int* __restrict__ overfull, int* __restrict__ off_grid,
                                                       int build_seq, SkinGate gate = SkinGate{nullptr},
-                                                      const int* __restrict__ ids_alt = nullptr) {
+                                                      const int* __restrict__ ids_alt = nullptr, CSoa3 vel = CSoa3{nullptr, nullptr, nullptr}) {
   if (gate.closed()) return;
+  // (skin step: the sort is on the REFERENCE positions x + tau v -- sph_device.hpp, SkinState::tau)
+  const float tau = REF ? gate.st->tau : 0.0f;
   // (skin step: `ids` is map 0, `ids_alt` map 1; the device state names the map that is current AFTER this rebuild,
   // so the one to read -- the order before the sort -- is the other)
   if (gate.st != nullptr && ids != nullptr && gate.st->ids_sel == 0) ids = ids_alt;
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   const int i = first + threadIdx.x;
   int cell = -1, id = 0;
   if (i < n) {
-    cell = sort_cell(c, px[i], py[i], pz[i]);
+    if constexpr (REF) cell = sort_cell(c, skin_ref(px[i], vel.x[i], tau), skin_ref(py[i], vel.y[i], tau), skin_ref(pz[i], vel.z[i], tau));
+    else cell = sort_cell(c, px[i], py[i], pz[i]);
     if (ids) id = ids[i];
     // PCISPH (OFF_GRID; the flag is never cleared: it holds the number of the last build that saw such a particle): does any particle lie outside the
     // grid's bounds, clamped into an outermost cell by the cell rule?  (false for NaN: that particle is nobody's neighbour)
@@ -250,10 +256,25 @@ struct ScatterOrder {
 // same-address atomics per 16M-particle build serialise in L2 and took 2.8 ms once the flow had
 // developed.  A byte per particle costs 32 MB of traffic and no atomics.)
 
+// the cell a particle is sorted into, and (skin step) the reference position that decides it
+struct SortPos {
+  float x, y, z;
+};
+template <bool REF>
+__device__ __forceinline__ SortPos sort_pos(const CSoa3& pos, const CSoa3& vel, float tau, int i) {
+  if constexpr (REF) return SortPos{skin_ref(pos.x[i], vel.x[i], tau), skin_ref(pos.y[i], vel.y[i], tau), skin_ref(pos.z[i], vel.z[i], tau)};
+  return SortPos{pos.x[i], pos.y[i], pos.z[i]};
+}
+template <bool REF>
 __device__ __forceinline__ void scatter_move(const ScatterArrays& a, const ScatterOrder& o, int i, int d, int id,
-                                             int* __restrict__ ids_dst) {
+                                             int* __restrict__ ids_dst, const Soa3& ref, const SortPos& sp) {
   ids_dst[d] = id;
   for (int f = 0; f < a.nf; ++f) a.dst[f][d] = a.src[f][i];
+  if constexpr (REF) {  // (skin step: the reference positions in sorted order -- what the lists are built at)
+    ref.x[d] = sp.x;
+    ref.y[d] = sp.y;
+    ref.z[d] = sp.z;
+  }
   if (o.dest) o.dest[i] = d;
 }
 
@@ -269,15 +290,20 @@ __device__ __forceinline__ ScatterIds skin_ids(const ScatterArrays& a, const Ski
   if (gate.st != nullptr && gate.st->ids_sel == 0) return ScatterIds{a.ids_dst, const_cast<int*>(a.ids_src)};  // 1 -> 0
   return ScatterIds{a.ids_src, a.ids_dst};
 }
+template <bool REF = false>
 __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                     const int* __restrict__ rank,
-                                                    const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr}) {
+                                                    const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr},
+                                                    CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},
+                                                    Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
   if (gate.closed()) return;
   const ScatterIds ids = skin_ids(a, gate);
+  const float tau = REF ? gate.st->tau : 0.0f;
   const int n = live_n(c);
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {  // (grid-stride: see k_cell_rank)
   bool later = false;
-  const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+  const SortPos sp = sort_pos<REF>(pos, vel, tau, i);
+  const int cell = sort_cell(c, sp.x, sp.y, sp.z);
   if (cell != c.ncell) {  // (a stale ghost is dropped)
     const int id = ids.src[i];
     const int s = cell_start[cell], r = rank[i];
@@ -300,25 +326,30 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
       }
     }
     if (later) o.keys[d] = id;
-    else scatter_move(a, o, i, d, id, ids.dst);
+    else scatter_move<REF>(a, o, i, d, id, ids.dst, ref, sp);
   }
   if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later ? 1 : 0;
   }
 }
 
+template <bool REF = false>
 __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                             const int* __restrict__ rank,
                                                             const int* __restrict__ cell_start,
-                                                            SkinGate gate = SkinGate{nullptr}) {
+                                                            SkinGate gate = SkinGate{nullptr},
+                                                            CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},
+                                                            Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
   if (gate.closed()) return;
   const ScatterIds ids = skin_ids(a, gate);
+  const float tau = REF ? gate.st->tau : 0.0f;
   if (o.cell_keys != nullptr) {
     // fallback of the one-pass ordering: only the marked cells with more than kCellKeys members are left, and only
     // if k_cell_rank has seen such a cell at all.  A small grid strides over the particles.
     if (*o.overfull == 0) return;
     const int n = live_n(c);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-      const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+      const SortPos sp = sort_pos<REF>(pos, vel, tau, i);
+      const int cell = sort_cell(c, sp.x, sp.y, sp.z);
       if (cell == c.ncell) continue;
       const int s = cell_start[cell], e = cell_start[cell + 1];
       if (e - s <= kCellKeys || !((o.unordered[cell >> 5] >> (cell & 31)) & 1u)) continue;
@@ -328,13 +359,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, Scatter
         const int key = o.keys[k];
         below += (key < id || (key == id && k < mine)) ? 1 : 0;
       }
-      scatter_move(a, o, i, s + below, id, ids.dst);
+      scatter_move<REF>(a, o, i, s + below, id, ids.dst, ref, sp);
     }
     return;
   }
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= live_n(c) || !o.later[i]) return;
-  const int cell = sort_cell(c, pos.x[i], pos.y[i], pos.z[i]);
+  const SortPos sp = sort_pos<REF>(pos, vel, tau, i);
+  const int cell = sort_cell(c, sp.x, sp.y, sp.z);
   const int id = ids.src[i];
   const int s = cell_start[cell], e = cell_start[cell + 1], mine = s + rank[i];
   int below = 0;
@@ -346,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter_ordered(DevConsts c, Scatter
 #pragma unroll
     for (int u = 0; u < 8; ++u) below += (key[u] < id || (key[u] == id && k0 + u < mine)) ? 1 : 0;
   }
-  scatter_move(a, o, i, s + below, id, ids.dst);
+  scatter_move<REF>(a, o, i, s + below, id, ids.dst, ref, sp);
 }
 
 // dst[dest[i]] = src[i]: a derived per-particle array follows the sort

@@ -38,6 +38,7 @@ constexpr int kLMaxChunks = 12;             // at most 95 listed neighbours per 
 constexpr int kLMaxEntries = kLMaxChunks * kLEntries - 1;
 constexpr int kLBlock = 512;                // 8 waves, two workgroups per CU (a tile's targets beyond 512 share lanes: for_each_target)
 constexpr unsigned int kLGlobal = 0xffffu;  // count sentinel: this particle takes the global-memory sweep
+constexpr float kSkinTauSteps = 16.0f;      // cap on SkinState::tau, in steps
 constexpr int kLQuads = 14;                 // staging: quads of 4 records per row and pass (36 rows x 14 = 504 lanes)
 static_assert(kTRows * kLQuads <= kLBlock, "one quad per lane");
 
@@ -56,10 +57,18 @@ __global__ void k_skin_decide(SkinState* st) {
     st->n_rebuilds += 1;
     st->unlisted = 0;
     st->fields_own = st->fields_padded = 0u;
+    // how far ahead of the particles this build's reference positions run: the fastest particle uses up `predict` of
+    // the budget at the build itself (vmax2: the previous step's velocities, i.e. the ones this build sorts; unknown
+    // after an upload -- +inf -- gives 0).  At most kSkinTauSteps steps: beyond that nothing was gained in the runs measured.
+    const float vmax = __builtin_sqrtf(__uint_as_float(st->vmax2_bits)) * (1.0f + 1.0e-6f);
+    float tau = 0.0f;
+    if (st->predict > 0.0f && vmax > 0.0f && vmax < 3.0e38f) tau = fminf(st->predict * st->budget / vmax, kSkinTauSteps * st->dt);
+    st->tau = tau;
   }
   st->disp = d;
   st->force = 0;
   st->disp2_bits = 0u;
+  st->vmax2_bits = 0u;
   st->n_steps += 1;
   // a step that rebuilds costs 4.8 ms where a step that does not costs 1.5 and the plain step 2.0 to 2.8 (16M): from one
   // rebuild in four or five steps on, the plain step is the faster one
@@ -466,7 +475,7 @@ template <bool WANT_G, bool WANT_V>
 __global__ __launch_bounds__(kLBlock, 4) void k_force_list(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                            const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                            const int* __restrict__ cell_start, SkinState* st, CSoa3 pX,
-                                                           CSoa3 vX, CSoa3 pZ, CSoa3 vZ, const float* __restrict__ rho,
+                                                           CSoa3 vX, CSoa3 pZ, CSoa3 vZ, CSoa3 pR, const float* __restrict__ rho,
                                                            const float* __restrict__ pterm,
                                                            const uint4* __restrict__ lists, int lstride, Soa3 pout,
                                                            Soa3 vout, DevStats* stats) {
@@ -695,8 +704,8 @@ __global__ __launch_bounds__(kLBlock, 4) void k_force_list(DevConsts c, TileGrid
       fy += c.ext[1];
       fz += c.ext[2];
       integrate_core(c, fx, fy, fz, px, py, pz, vx, vy, vz, vbits, fbits);
-      {  // how far from where the lists were built (the sort's output: slot order has not changed since)
-        const float ex = px - pZ.x[g], ey = py - pZ.y[g], ez = pz - pZ.z[g];
+      {  // how far from the reference position its list was built at (the sort's output: slot order has not changed since)
+        const float ex = px - pR.x[g], ey = py - pR.y[g], ez = pz - pR.z[g];
         const unsigned int db = nonneg_bits(__builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)));
         dbits = db > dbits ? db : dbits;
       }
@@ -711,6 +720,7 @@ __global__ __launch_bounds__(kLBlock, 4) void k_force_list(DevConsts c, TileGrid
   wave_atomic_max(&stats->max_vel_bits, vbits);
   wave_atomic_max(&stats->max_f_bits, fbits);
   wave_atomic_max(&st->disp2_bits, dbits);
+  wave_atomic_max(&st->vmax2_bits, vbits);  // (what the next rebuild's tau is chosen by: |v| before the walls, >= the stored one)
 }
 
 }  // namespace dsl

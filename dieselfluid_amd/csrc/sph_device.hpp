@@ -113,6 +113,13 @@ struct SkinState {
   int n_live;       // particles
   // of the last rebuild: list fields the targets need, and fields they hold once padded to their wave's longest list
   unsigned int fields_own, fields_padded;
+  // Lists are built at REFERENCE positions x + tau v (where the particle will be about half way through the lists' life)
+  // rather than where it is at the build: the same budget then covers the way from -tau v to +tau v around the
+  // reference -- up to twice the steps (profiles/r04_ballistic_skin.jsonl).  Any reference is sound: displacement is
+  // measured against it, and |tau v| <= predict * budget holds at the build because vmax2 is the true maximum.
+  float tau;                // time by which this build's reference positions run ahead (0: none)
+  float predict;            // fraction of the budget the build itself may use up (DSL_OPT_SKIN_PREDICT; 0: references = positions)
+  unsigned int vmax2_bits;  // max |v|^2 of the velocities the last step stored (bits; +inf: unknown)
 };
 // the gate every kernel of the rebuild chain takes (st == nullptr: no gate, the kernel always runs)
 struct SkinGate {

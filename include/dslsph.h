@@ -461,6 +461,13 @@ enum {
   DSL_OPT_DEVICE_BYTES = 6,       /* (get) device memory this handle has allocated so far */
   DSL_OPT_SKIN_FIELDS_OWN = 7,    /* (get, while skin steps are live) list fields the particles needed at the last rebuild ... */
   DSL_OPT_SKIN_FIELDS_PADDED = 8, /* ... and the fields their lists hold, padded to the longest list of each wave */
+  DSL_OPT_SKIN_PREDICT = 9,       /* (set/get) in [0, 0.95], default 0.8: the lists are built at REFERENCE positions x + tau v --
+                                     where a particle will be about half way through the lists' life -- and displacement is
+                                     measured against those: the same budget s h / 2 then covers the way from -tau v to
+                                     +tau v.  tau is chosen on the device at every rebuild so that the fastest particle
+                                     uses this fraction of the budget at the build itself (at most 16 steps ahead); any
+                                     reference is sound, the displacement test is the same.  0: built where the particles are */
+  DSL_OPT_SKIN_TAU_STEPS = 10,    /* (get, while skin steps are live) tau of the last rebuild, in steps */
   /* the kernels' fall-back forms (A/B runs and tests; the defaults are the product).  Each is product code that some
    * configuration or failure path reaches, and tests/test_gpu_variants.py holds each to the default's parity bar. */
   DSL_OPT_DENSITY_PAIR = 16,      /* 1: FAST density sweep with two targets per lane (default); 0: one lane per target */

@@ -78,6 +78,39 @@ def test_skin_equals_plain_steps_to_tolerance_and_is_reproducible():
     assert helpers.rel_err(a[2], plain[2]) < 2e-5
 
 
+def test_lists_built_at_predicted_positions_live_longer():
+    """DSL_OPT_SKIN_PREDICT: a rebuild sorts, sweeps and lists at the REFERENCE positions x + tau v and displacement is
+    measured against those, so the budget s h / 2 covers the way from -tau v to +tau v.  A block drifting at 0.01 h per
+    step (s = 0.1: 5 steps per build when built where the particles are) must need fewer rebuilds with the prediction
+    than without, report its tau, and match the oracle -- which has no lists at all -- either way; two predicted runs
+    agree bit for bit (tau is device state, a function of the simulation alone)."""
+    n3 = 16
+    p, pos, frc = _scene(n3)
+    vel = np.zeros_like(pos)
+    vel[:, 0] = 0.01 * p.h / p.dt
+    steps = 40
+    ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel, force=frc)
+    ora.wcsph_step(steps)
+    rebuilds, runs = {}, []
+    for predict in (0.0, 0.8, 0.8):
+        eng = _engine(p, pos, 0.1, vel)
+        eng.set_option("skin_predict", predict)
+        assert eng.get_option("skin_predict") == pytest.approx(predict)
+        eng.wcsph_step(steps)
+        tau = eng.get_option("skin_tau_steps")
+        assert eng.get_option("skin_steps") == steps and eng.get_option("skin_list_overflow") == 0
+        rebuilds[predict] = eng.get_option("skin_rebuilds")
+        assert (tau == 0.0) if predict == 0.0 else (2.0 < tau <= 16.0), tau  # 0.8 x 0.05 h / (0.01 h per step) = 4 steps
+        _check(eng, ora, p, steps)
+        runs.append((eng.download("positions"), eng.download("velocities")))
+        eng.close()
+    assert 6 <= rebuilds[0.0] <= 12 and rebuilds[0.8] <= rebuilds[0.0] - 2, rebuilds
+    assert np.array_equal(runs[1][0].view(np.uint32), runs[2][0].view(np.uint32))
+    assert np.array_equal(runs[1][1].view(np.uint32), runs[2][1].view(np.uint32))
+    with pytest.raises(Exception):
+        _engine(p, pos, 0.1).set_option("skin_predict", 1.5)
+
+
 def test_a_fast_particle_forces_rebuilds():
     """One particle shot through the block at 0.3 h per step: the displacement bound is outrun every step, every step
     rebuilds, and the results still match the oracle (which has no lists at all)."""
