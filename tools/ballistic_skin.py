@@ -34,12 +34,16 @@ eng.upload("positions", pos); eng.reset_forces(); del pos
 done = 0
 taus = [float(v) for v in a.taus.split(",")]
 for at in [int(v) for v in a.at.split(",")]:
-    while done < at:
-        k = min(500, at - done); eng.wcsph_step(k); done += k
+    while done < at - 1:
+        k = min(500, at - 1 - done); eng.wcsph_step(k); done += k
+    vm1 = torch.from_numpy(eng.download("velocities")).to(dev).double()
+    eng.wcsph_step(1); done += 1
     x0 = torch.from_numpy(eng.download("positions")).to(dev).double()
     v0 = torch.from_numpy(eng.download("velocities")).to(dev).double()
+    a0 = (v0 - vm1) / dt  # the acceleration of the last step: a second-order reference x0 + tau v0 + tau^2 a0 / 2
     vmax = float(v0.norm(dim=1).max()) * dt / h
     table = {str(t): [] for t in taus}
+    table2 = {str(t): [] for t in taus}
     for k in range(0, a.kmax + 1):
         if k > 0:
             eng.wcsph_step(1); done += 1
@@ -49,13 +53,18 @@ for at in [int(v) for v in a.at.split(",")]:
         d = (x - x0) / h
         for t in taus:
             table[str(t)].append(float((d - (t * dt / h) * v0).norm(dim=1).max()))
-    life = {}
-    for t in taus:
-        row = table[str(t)]
-        n = 0
-        while n < len(row) and row[n] <= budget:
-            n += 1
-        life[str(t)] = n - 1 if n > 0 else -1  # last k that was still inside the budget (kmax: never left it); -1: the reference itself is outside
+            table2[str(t)].append(float((d - (t * dt / h) * v0 - (0.5 * (t * dt) ** 2 / h) * a0).norm(dim=1).max()))
+    def lives(tab):
+        life = {}
+        for t in taus:
+            row = tab[str(t)]
+            n = 0
+            while n < len(row) and row[n] <= budget:
+                n += 1
+            life[str(t)] = n - 1 if n > 0 else -1  # last k that was still inside the budget (kmax: never left it); -1: the reference itself is outside
+        return life
+    life = lives(table)
     print(json.dumps({"at_step": at, "s": a.s, "budget_over_h": budget, "max_v_dt_over_h": vmax, "steps_inside_budget": life,
+                      "steps_inside_budget_second_order": lives(table2),
                       "max_dev_over_h": {t: [round(v, 5) for v in row[:: max(1, a.kmax // 16)]] for t, row in table.items()}}), flush=True)
 eng.close()
