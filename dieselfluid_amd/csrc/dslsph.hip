@@ -162,6 +162,7 @@ struct dsl_handle {
   float* pvz[6] = {};  // the sort's output set of a skin step (Z)
   float* pvr[3] = {};  // ... and the build's reference positions x + tau v in the same order (SkinState::tau)
   float skin_predict = kSkinPredict;  // DSL_OPT_SKIN_PREDICT
+  bool list_build_lockstep = true;    // DSL_OPT_LIST_BUILD
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
@@ -1728,8 +1729,12 @@ int skin_step(dsl_handle* h) {
     hipLaunchKernelGGL((k_density_pair<true, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
                        h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pR, h->rho, h->pterm, h->nmask,
                        h->cap, wide_thr, gate);
-    hipLaunchKernelGGL(k_list_build, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
-                       h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pR, wide_thr);
+    if (h->list_build_lockstep)
+      hipLaunchKernelGGL(k_list_build, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+                         h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pR, wide_thr);
+    else
+      hipLaunchKernelGGL(k_list_build_v1, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+                         h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pR, wide_thr);
   });
   if (rc) return rc;
   // the step itself: densities and the fused force + integrate over the lists
@@ -1848,6 +1853,7 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
     case DSL_OPT_PCI_QTILED: h->pci_qtiled = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QPAIR: h->pci_qpair = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: h->pci_qrows = value != 0.0; return DSL_OK;
+    case DSL_OPT_LIST_BUILD: h->list_build_lockstep = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QINCR:
       h->pci_qincr = value != 0.0;
       h->pci_rows_live = false;
@@ -1884,6 +1890,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_PCI_QTILED: *value = h->pci_qtiled ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QPAIR: *value = h->pci_qpair ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: *value = h->pci_qrows ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_LIST_BUILD: *value = h->list_build_lockstep ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QINCR: *value = h->pci_qincr ? 1.0 : 0.0; return DSL_OK;
     default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
   }

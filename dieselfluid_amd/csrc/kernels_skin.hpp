@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned int pad_entry(const TileMeta& m) { return (u
 //     then a scalar one -- no per-lane counters, no ballots, no selects between "my next chunk" and padding;
 //   * a target of a short pass keeps its own length in field 0 (its k lanes split the chunks among them).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+__global__ __launch_bounds__(kLBlock) void k_list_build_v1(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                         const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                         const unsigned int* __restrict__ nmask, int mstride,
                                                         uint4* __restrict__ lists, int lstride, SkinState* st,
@@ -214,6 +214,186 @@ __global__ __launch_bounds__(kLBlock) void k_list_build(DevConsts c, TileGrid tg
         if (fits) lists[(size_t)ch * lstride + g] = v;
       }
       if (!fits) lists[g] = make_uint4(kLGlobal, 0u, 0u, 0u);
+    });
+    if (have) tile_meta_store(metas[cur ^ 1], table_word);
+    sync_lds();
+    if (tid == 0) {
+      atomicAdd(&st->fields_own, tile_fields[0]);
+      atomicAdd(&st->fields_padded, tile_fields[1]);
+      tile_fields[0] = tile_fields[1] = 0u;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// The same lists, built in lock step (round 4; k_list_build_v1 above is the first form, kept as DSL_OPT_LIST_BUILD = 0).
+// v1 walks a target's 18 mask words one `while (w)` loop after the other: every loop lasts as long as the wave's busiest
+// lane (~97 trips for ~38 entries), and a lane finishes its chunks at its own pace (hence `held`).  Here a lane first
+// puts its NON-EMPTY words, each with the record its bit 0 stands for, into a queue of its own in LDS ([item][lane]:
+// conflict-free whatever the item index); the wave's longest list is known from the popcounts before a single entry
+// exists, and ONE scalar loop over that many fields follows in which every lane produces exactly one field per trip --
+// the next bit of its current word (the next word when that is exhausted), or the far-away record once its list has
+// ended.  All lanes complete chunk c in the same trip: a chunk leaves as one 1 KB store per wave, straight from
+// registers.  Entry order, padding and field 0 are v1's: the two kernels write the same bytes (but for the entries of
+// runs without masks, which v1 has in their run's place and ascending, this one last and descending).
+// ---------------------------------------------------------------------------------
+constexpr int kLQueue = 24;  // queue items per target: 18 mask words + the words of runs without masks (more: unlisted)
+__global__ __launch_bounds__(kLBlock, 4) void k_list_build(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
+                                                        const int* __restrict__ n_tiles, const int* __restrict__ desc,
+                                                        const unsigned int* __restrict__ nmask, int mstride,
+                                                        uint4* __restrict__ lists, int lstride, SkinState* st,
+                                                        SkinGate gate, CSoa3 p, float wide_thr) {
+  if (gate.closed()) return;
+  __shared__ TileMeta metas[2];
+  __shared__ unsigned int qword[kLQueue][kLBlock];
+  __shared__ unsigned short qtop[kLQueue][kLBlock];
+  __shared__ unsigned int tile_fields[2];
+  const int tid = threadIdx.x;
+  if (tid < 2) tile_fields[tid] = 0u;
+  TileFeed feed(desc_of, *n_tiles);
+  int di = 0;
+  bool have = feed.pop(di);
+  if (have) tile_meta_store(metas[0], tile_meta_request(desc, di));
+  for (int cur = 0; have; cur ^= 1) {
+    const TileMeta& m = metas[cur];
+    sync_lds();  // this tile's table is visible, the other copy is free
+    have = feed.pop(di);
+    int table_word = 0;
+    if (have) table_word = tile_meta_request(desc, di);
+    const int ntarg = m.tprefix[kTB * kTB];
+    const unsigned int pad = pad_entry(m);
+    if (m.overflow != 0 && tid == 0) atomicAdd(&st->unlisted, ntarg);
+    for_each_target<true, kLBlock>(ntarg, tid, tid, [&](auto shared_c, int t, int sub, int k) {
+      constexpr bool SHARED = decltype(shared_c)::value;
+      if (SHARED && sub != 0) return;  // (a short pass's list is built by the first lane of its group)
+      const TileTarget tt = tile_target(m, t);
+      const int g = tt.g;
+      const bool masks = m.overflow == 0;  // (a tile beyond the LDS budget was not swept: the global-memory sweep)
+      // ---- the queue: non-empty mask words in v1's order, own record struck out, and their popcount
+      int nq = 0, total = 0;
+      bool too_many = false;
+      auto enqueue = [&](unsigned int w, int top) {
+        if (w != 0u) {
+          if (nq < kLQueue) {
+            qword[nq][tid] = w;
+            qtop[nq][tid] = (unsigned short)top;
+          } else {
+            too_many = true;
+          }
+          nq += 1;
+          total += __builtin_popcount(w);
+        }
+      };
+      if (masks) {
+        unsigned int run[9], w1[9], w2[9];  // (a run's LDS records: first | end << 16, as the tile table packs them)
+        unsigned int unmasked = 0u;
+#pragma unroll
+        for (int ri = 0; ri < 9; ++ri) {  // (all loads in flight together)
+          run[ri] = (unsigned int)m.run[(tt.srow + (ri / 3 - 1) * kTH + (ri % 3 - 1)) * kTB + tt.lx - 1];
+          const int len = (int)(run[ri] >> 16) - (int)(run[ri] & 0xffffu);
+          w1[ri] = (len > 0 && len <= 64) ? nmask[(size_t)ri * mstride + g] : 0u;
+          w2[ri] = (len > 32 && len <= 64) ? nmask[(size_t)(kMaskHigh + ri) * mstride + g] : 0u;
+          if (len > 64) unmasked |= 1u << ri;
+        }
+#pragma unroll
+        for (int ri = 0; ri < 9; ++ri) {
+          const int j = (int)(run[ri] & 0xffffu), len = (int)(run[ri] >> 16) - j;
+          // bit b of a mask word <-> record top - b, top counted from the chunk's length rounded up to the sweep's unroll of 4
+          unsigned int a = w1[ri], b = w2[ri];
+          const int top1 = j + ((min(len, 32) + 3) & ~3) - 1;
+          const int top2 = j + 32 + ((len - 32 + 3) & ~3) - 1;
+          if (ri == 4) {  // (the particle itself is no entry: sph_field.go:164; its record lies in its own row's run)
+            const int b1 = top1 - tt.own, b2 = top2 - tt.own;
+            if (b1 >= 0 && b1 < 32) a &= ~(1u << b1);
+            if (b2 >= 0 && b2 < 32) b &= ~(1u << b2);
+          }
+          enqueue(a, top1);
+          enqueue(b, top2);
+        }
+        // runs without masks (rare: three cells of more than 21 particles each) come last: the sweep's test, from global
+        // memory, 32 records per word (bit b <-> record top - b, as in the masks)
+        while (unmasked != 0u) {
+          const int ri = __builtin_ctz(unmasked);
+          unmasked &= unmasked - 1u;
+          const int rr = tt.srow + (ri / 3 - 1) * kTH + (ri % 3 - 1);
+          int j, je;
+          tile_run(m, rr, tt.lx, j, je);
+          const int g0 = m.row_gs[rr] - m.row_lds[rr];  // global slot of LDS record r of this row: g0 + r
+          const float xi = p.x[g], yi = p.y[g], zi = p.z[g];
+          for (int r0 = j; r0 < je; r0 += 32) {
+            unsigned int w = 0u;
+            const int top = r0 + 31;
+            for (int r = r0; r < min(r0 + 32, je); ++r) {
+              const float dx = xi - p.x[g0 + r], dy = yi - p.y[g0 + r], dz = zi - p.z[g0 + r];
+              const float tq = __builtin_fmaf(-dist2<true>(dx, dy, dz), c.inv_hh, 1.0f);
+              if (tq > wide_thr && r != tt.own) w |= 1u << (top - r);
+            }
+            enqueue(w, top);
+          }
+        }
+      }
+      const int n_own = 1 + total;  // fields, the length's included
+      const bool fits = masks && !too_many && n_own <= kLMaxChunks * kLEntries;
+      if (masks && !fits) st->list_overflow = 1;  // (benign race: every writer stores 1)
+      int fields = fits ? n_own : 0;
+      const int own_fields = fields;
+      // the longest list of the lanes that are here (a full pass pads every list to it; a short pass only runs that long)
+      int wmax = 0;
+#pragma unroll
+      for (int bit = 6; bit >= 0; --bit) {
+        const int cand = wmax | (1 << bit);
+        if (__builtin_amdgcn_ballot_w64(fields >= cand) != 0ull) wmax = cand;
+      }
+      if constexpr (!SHARED) fields = fits ? wmax : 0;
+      // statistics of the build (DSL_OPT_SKIN_FIELDS_*): summed in LDS, one pair of global atomics per tile
+      atomicAdd(&tile_fields[0], (unsigned int)own_fields);
+      atomicAdd(&tile_fields[1], (unsigned int)fields);
+      const int nch = (fields + kLEntries - 1) / kLEntries;       // this lane's chunks (full pass: the wave's)
+      const int nch_wave = (wmax + kLEntries - 1) / kLEntries;    // the loop's
+      // ---- one field per trip and lane
+      unsigned int b0 = 0u, b1 = 0u, b2 = 0u, b3 = 0u;            // a 128-bit shift register: field k of a chunk ends up in bits 16k .. 16k+15
+      unsigned int k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;            // chunk 0, kept for its length field
+      int qi = 0;
+      unsigned int w = 0u, top = 0u;
+      // (the next item is fetched one trip before it is needed)
+      unsigned int wn = (fits && nq > 0) ? qword[0][tid] : 0u, tn = (fits && nq > 0) ? qtop[0][tid] : 0u;
+      const int nq_live = fits ? nq : 0;
+      for (int it = 0; it < nch_wave * kLEntries; ++it) {
+        unsigned int entry = pad;
+        if (it == 0) {
+          entry = 0u;  // the length's field
+        } else {
+          if (w == 0u && qi < nq_live) {
+            w = wn;
+            top = tn;
+            qi += 1;
+            if (qi < nq_live) {
+              wn = qword[qi][tid];
+              tn = qtop[qi][tid];
+            }
+          }
+          if (w != 0u) {
+            const int b = __builtin_ctz(w);
+            w &= w - 1u;
+            entry = (top - (unsigned int)b) << 4;
+          }
+        }
+        b0 = __builtin_amdgcn_alignbit(b1, b0, 16);
+        b1 = __builtin_amdgcn_alignbit(b2, b1, 16);
+        b2 = __builtin_amdgcn_alignbit(b3, b2, 16);
+        b3 = (b3 >> 16) | (entry << 16);
+        if ((it & (kLEntries - 1)) == kLEntries - 1) {
+          const int ch = it >> 3;
+          if (ch == 0) {
+            k0 = b0, k1 = b1, k2 = b2, k3 = b3;
+          } else if (ch < nch) {
+            lists[(size_t)ch * lstride + g] = make_uint4(b0, b1, b2, b3);
+          }
+        }
+      }
+      // field 0 of the first chunk is the length (or the mark of an unlisted target)
+      if (fits) lists[g] = make_uint4((k0 & 0xffff0000u) | (unsigned int)fields, k1, k2, k3);
+      else lists[g] = make_uint4(kLGlobal, 0u, 0u, 0u);
     });
     if (have) tile_meta_store(metas[cur ^ 1], table_word);
     sync_lds();

@@ -478,6 +478,8 @@ enum {
   DSL_OPT_PCI_QPAIR = 21,         /* ... two queries of one cell per lane (default 1) */
   DSL_OPT_PCI_QROWS = 22,         /* ... per-cell query rows instead of a sorted array (default 1; 512 B per GRID CELL,
                                      allocated when the binned form is first used: 33 GB for the 64M scene's box) */
+  DSL_OPT_LIST_BUILD = 24,        /* skin step: 1 the lists are built in lock step -- every lane of a wave produces one field per trip
+                                     from a queue of its non-empty mask words (default); 0: one bit loop per mask word */
   DSL_OPT_PCI_QINCR = 23          /* ... the rows kept from one correction iteration of a step to the next: only a query that
                                      has changed cells is moved (default 1; 0: every iteration fills the rows afresh) */
 };

@@ -111,6 +111,32 @@ def test_lists_built_at_predicted_positions_live_longer():
         _engine(p, pos, 0.1).set_option("skin_predict", 1.5)
 
 
+def test_both_list_builders_write_the_same_lists():
+    """DSL_OPT_LIST_BUILD: the lock-step builder (every lane one field per trip, from a queue of its non-empty mask words)
+    and the first form (one bit loop per mask word) produce the same entries in the same order with the same padding, so
+    two runs that differ only in the builder end in the same bits -- over 25 steps with several rebuilds, from rest and
+    with seeded velocities (lists of very different lengths inside a wave)."""
+    n3 = 24
+    p, pos, _ = _scene(n3)
+    cs = float(np.sqrt(p.eos_w / p.mass))
+    for vel in (None, helpers.seeded_velocities(n3 ** 3, scale=0.02 * cs)):
+        out = []
+        for lockstep in (1, 0):
+            eng = _engine(p, pos, 0.1, vel)
+            eng.set_option("list_build", lockstep)
+            assert eng.get_option("list_build") == lockstep
+            eng.wcsph_step(25)
+            assert eng.get_option("skin_steps") == 25 and eng.get_option("skin_rebuilds") >= 2
+            assert eng.get_option("skin_list_overflow") == 0
+            out.append((eng.download("positions"), eng.download("velocities"), eng.download("densities"),
+                        eng.get_option("skin_rebuilds"), eng.get_option("skin_fields_own"), eng.get_option("skin_fields_padded")))
+            eng.close()
+        a, b = out
+        assert a[3:] == b[3:], (a[3:], b[3:])
+        for k in range(3):
+            assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
 def test_a_fast_particle_forces_rebuilds():
     """One particle shot through the block at 0.3 h per step: the displacement bound is outrun every step, every step
     rebuilds, and the results still match the oracle (which has no lists at all)."""

@@ -42,5 +42,31 @@ PYEOF
 import json,sys
 r=[json.loads(l) for l in open('gpurun_out/r4/soak_${n3}.jsonl')][-$runs:]
 print('digests', [x['state_sha1'] for x in r]); sys.exit(0 if len({x['state_sha1'] for x in r})==1 and all(x['bad_at'] is None for x in r) else 1)"; exit $? ;;
+  stats)        # tools/gpu_r04.sh stats <tag> <bench args...>: rocprofv3 kernel stats of one bench command, launches > 30 us only
+    tag=$1; shift
+    out=$GRAFT_REPO_ROOT/gpurun_out/r4/stats_$tag; mkdir -p $out
+    export TMPDIR=/tmp; cd /tmp
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_$tag -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 "$@" > $out/bench.json 2> $out/stats.err || exit 1
+    cp $(find /tmp/stats_$tag -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+    python3 - $(find /tmp/stats_$tag -name "*kernel_trace.csv" | head -1) > $out/long_launches.txt <<'PYEOF'
+import csv, sys, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
+    big = [x for x in v if x > 30.0]
+    print(f"{k}: n={len(v)} total_us={sum(v):.0f} long={len(big)} mean_long_us={(sum(big)/len(big) if big else 0):.1f} min_long={(min(big) if big else 0):.1f}")
+PYEOF
+    cat $out/long_launches.txt | head -14; exit 0 ;;
+  skin_sweep)   # tools/gpu_r04.sh skin_sweep <tag> "<s values>" "<predict values>" [bench args]: the bench line per (s, predict)
+    tag=$1; ss=$2; ps=$3; shift 3
+    : > gpurun_out/r4/skin_sweep_$tag.jsonl
+    for s in $ss; do for p in $ps; do
+      timeout -k 10 300 python bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 --skin $s --opt skin_predict=$p "$@" 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=r['skin']
+print(json.dumps({'s': $s, 'predict': $p, 'value': r['value'], 'ms_per_step': r['ms_per_step'], 'rebuilds': k['rebuilds_in_timed_region'], 'tau_steps': k['tau_steps_last_rebuild'], 'fields_walked': k['fields_walked_per_particle'], 'density_ms': r['kernels_ms']['density'], 'force_ms': r['kernels_ms']['force_integrate'], 'suspensions': k['suspensions']}))" >> gpurun_out/r4/skin_sweep_$tag.jsonl || exit 1
+      tail -1 gpurun_out/r4/skin_sweep_$tag.jsonl
+    done; done; exit 0 ;;
   *) echo "unknown: $what"; exit 2 ;;
 esac
