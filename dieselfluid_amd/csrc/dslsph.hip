@@ -42,7 +42,7 @@ std::string g_create_error;
 // DSL_OPT_SKIN of a DSL_MATH_FAST handle ...  (0.08: measured best of 0.06 .. 0.10 on the 16M lattice -- 9234 / 9387 /
 // 9288 M particle-steps/s, profiles/r04 -- and a tile of 4 x 4 x 3 such cells stays a fifth below the LDS image's kTCap
 // records where 0.10 sits at its edge: at 0.11 the lattice's fullest tiles no longer fit and the step takes 3.4 ms)
-constexpr float kSkinDefault = 0.08f;
+constexpr float kSkinDefault = 0.07f;  // (0.08 before the lists were built at predicted positions: profiles/r04_skin_sweep_predict.jsonl)
 // the lists are built where the particles will be about half way through the lists' life: the fastest particle may use up
 // this fraction of the displacement budget at the build itself (DSL_OPT_SKIN_PREDICT; 0: built where the particles are)
 constexpr float kSkinPredict = 0.8f;
@@ -163,6 +163,7 @@ struct dsl_handle {
   float* pvr[3] = {};  // ... and the build's reference positions x + tau v in the same order (SkinState::tau)
   float skin_predict = kSkinPredict;  // DSL_OPT_SKIN_PREDICT
   bool list_build_lockstep = true;    // DSL_OPT_LIST_BUILD
+  int grid_oversub = 8;               // DSL_OPT_GRID_OVERSUB
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
@@ -593,8 +594,14 @@ bool use_tiled(const dsl_handle* h) {
   if (h->c.wcsph_viscosity && h->c.visc_running_mass && h->c.mass != 1.0f) return false;
   return true;
 }
-int persistent_grid(const dsl_handle* h, int blocks_per_cu) {
-  int g = 256 * blocks_per_cu;
+// `lists`: the skin step's list kernels -- their tiles cost the same and their workgroups stay persistent
+int persistent_grid(const dsl_handle* h, int blocks_per_cu, bool lists = false) {
+  // DSL_OPT_GRID_OVERSUB (default 8): eight times the workgroups the chip holds, each with an eighth of the share -- the
+  // hardware hands them out as workgroups retire, which evens out tiles of unequal cost: developed flow density 0.96 ->
+  // 0.89 ms, force 1.29 -> 1.24, lattice 0.64 -> 0.61 / 0.86 -> 0.83 (profiles/r04_grid_oversub.jsonl; 16 and 32: less)
+  // (not on slab ranks or small scenes: a rank of 16M / 8 -- 6k tiles -- measured 0.42 -> 0.43 ms per step with it)
+  const bool over = !lists && h->c.slab_axis < 0 && h->tg.ntiles >= 16384;
+  int g = 256 * blocks_per_cu * (over ? h->grid_oversub : 1);
   // (tests: DSL_PERSISTENT_BLOCKS caps the grid, so that a small scene makes every workgroup walk MANY tiles -- the
   // tile-to-tile hand-over inside a workgroup is where the double-buffered loops can go wrong, and a test scene of a
   // few hundred tiles otherwise gives each workgroup one)
@@ -1726,27 +1733,27 @@ int skin_step(dsl_handle* h) {
   const double reach = 1.0 + (double)h->skin;
   const float wide_thr = (float)(1.0 - reach * reach * 1.0004 - 1.0e-4);
   rc = timed(h, DSL_K_NEIGH_LISTS, [&] {
-    hipLaunchKernelGGL((k_density_pair<true, true>), dim3(persistent_grid(h, 8)), dim3(kPBlock), 0, h->stream, c, h->tg,
+    hipLaunchKernelGGL((k_density_pair<true, true>), dim3(persistent_grid(h, 8, true)), dim3(kPBlock), 0, h->stream, c, h->tg,
                        h->tile_desc_of, h->n_tiles, h->tile_desc, h->cell_start, bnd_of(h), pR, h->rho, h->pterm, h->nmask,
                        h->cap, wide_thr, gate);
     if (h->list_build_lockstep)
-      hipLaunchKernelGGL(k_list_build, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+      hipLaunchKernelGGL(k_list_build, dim3(persistent_grid(h, 2, true)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
                          h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pR, wide_thr);
     else
-      hipLaunchKernelGGL(k_list_build_v1, dim3(persistent_grid(h, 2)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+      hipLaunchKernelGGL(k_list_build_v1, dim3(persistent_grid(h, 2, true)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
                          h->n_tiles, h->tile_desc, h->nmask, h->cap, h->lists, h->cap, st, gate, pR, wide_thr);
   });
   if (rc) return rc;
   // the step itself: densities and the fused force + integrate over the lists
   rc = timed(h, DSL_K_DENSITY, [&] {
-    hipLaunchKernelGGL(k_density_list, dim3(persistent_grid(h, 3)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
+    hipLaunchKernelGGL(k_density_list, dim3(persistent_grid(h, 3, true)), dim3(kLBlock), 0, h->stream, c, h->tg, h->tile_desc_of,
                        h->n_tiles, h->tile_desc, h->cell_start, st, pX, pZ, h->lists, h->cap, h->rho, h->pterm);
   });
   if (rc) return rc;
   const Soa3 po = mpos(h, Y), vo = mvel(h, Y);
   const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
-    dim3 g(persistent_grid(h, 2)), b(kLBlock);
+    dim3 g(persistent_grid(h, 2, true)), b(kLBlock);
 #define DSL_LAUNCH_FL(GG, VV)                                                                                             \
   hipLaunchKernelGGL((k_force_list<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, h->tile_desc,       \
                      h->cell_start, st, pX, vX, pZ, vZ, pR, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats)
@@ -1854,6 +1861,10 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
     case DSL_OPT_PCI_QPAIR: h->pci_qpair = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: h->pci_qrows = value != 0.0; return DSL_OK;
     case DSL_OPT_LIST_BUILD: h->list_build_lockstep = value != 0.0; return DSL_OK;
+    case DSL_OPT_GRID_OVERSUB:
+      if (!(value >= 1.0 && value <= 64.0)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_GRID_OVERSUB is a factor in [1, 64]");
+      h->grid_oversub = (int)value;
+      return DSL_OK;
     case DSL_OPT_PCI_QINCR:
       h->pci_qincr = value != 0.0;
       h->pci_rows_live = false;
@@ -1891,6 +1902,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_PCI_QPAIR: *value = h->pci_qpair ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: *value = h->pci_qrows ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_LIST_BUILD: *value = h->list_build_lockstep ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_GRID_OVERSUB: *value = (double)h->grid_oversub; return DSL_OK;
     case DSL_OPT_PCI_QINCR: *value = h->pci_qincr ? 1.0 : 0.0; return DSL_OK;
     default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
   }

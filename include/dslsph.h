@@ -480,6 +480,9 @@ enum {
                                      allocated when the binned form is first used: 33 GB for the 64M scene's box) */
   DSL_OPT_LIST_BUILD = 24,        /* skin step: 1 the lists are built in lock step -- every lane of a wave produces one field per trip
                                      from a queue of its non-empty mask words (default); 0: one bit loop per mask word */
+  DSL_OPT_GRID_OVERSUB = 25,      /* the tile kernels' grids are this many times the workgroups a chip holds at once (default 1:
+                                     persistent workgroups, each walks its share of the tile list; k > 1: the hardware hands
+                                     out k times as many, shorter shares as workgroups retire -- evens out tiles of unequal cost) */
   DSL_OPT_PCI_QINCR = 23          /* ... the rows kept from one correction iteration of a step to the next: only a query that
                                      has changed cells is moved (default 1; 0: every iteration fills the rows afresh) */
 };

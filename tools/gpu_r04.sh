@@ -58,6 +58,26 @@ for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     print(f"{k}: n={len(v)} total_us={sum(v):.0f} long={len(big)} mean_long_us={(sum(big)/len(big) if big else 0):.1f} min_long={(min(big) if big else 0):.1f}")
 PYEOF
     cat $out/long_launches.txt | head -14; exit 0 ;;
+  ab)           # tools/gpu_r04.sh ab <tag> "<variant names>" <reps> [bench args]: builds of tools/build_variant.sh, interleaved, in one call
+    tag=$1; names=$2; reps=$3; shift 3
+    : > gpurun_out/r4/ab_$tag.jsonl
+    for r in $(seq 1 $reps); do for v in $names; do
+      DSL_LIB=$GRAFT_REPO_ROOT/variants/libdslsph_$v.so timeout -k 10 300 python bench.py --no-cpu-baseline --developed-steps 0 --exact-steps 0 "$@" 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=r.get('skin') or {}
+print(json.dumps({'variant': '$v', 'value': r['value'], 'ms_per_step': r['ms_per_step'], 'rebuilds': k.get('rebuilds_in_timed_region'), 'density_ms': r['kernels_ms'].get('density'), 'force_ms': r['kernels_ms'].get('force_integrate'), 'developed': (r.get('developed') or {}).get('value'), 'drifted': (r.get('drifted') or {}).get('value')}))" >> gpurun_out/r4/ab_$tag.jsonl || exit 1
+      tail -1 gpurun_out/r4/ab_$tag.jsonl
+    done; done; exit 0 ;;
+  opt_ab)       # tools/gpu_r04.sh opt_ab <tag> "<opt settings, e.g. grid_oversub=1 grid_oversub=4>" <reps> [bench args]: one build, library options interleaved
+    tag=$1; opts=$2; reps=$3; shift 3
+    : > gpurun_out/r4/opt_ab_$tag.jsonl
+    for r in $(seq 1 $reps); do for o in $opts; do
+      timeout -k 10 500 python bench.py --no-cpu-baseline --exact-steps 0 --opt $o "$@" 2>/dev/null | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=r.get('skin') or {}; d=r.get('developed') or {}
+print(json.dumps({'opt': '$o', 'value': r['value'], 'ms_per_step': r['ms_per_step'], 'rebuilds': k.get('rebuilds_in_timed_region'), 'density_ms': r['kernels_ms'].get('density'), 'force_ms': r['kernels_ms'].get('force_integrate'), 'developed': d.get('value'), 'developed_kernels': d.get('kernels_ms'), 'drifted': (r.get('drifted') or {}).get('value')}))" >> gpurun_out/r4/opt_ab_$tag.jsonl || exit 1
+      tail -1 gpurun_out/r4/opt_ab_$tag.jsonl
+    done; done; exit 0 ;;
   skin_sweep)   # tools/gpu_r04.sh skin_sweep <tag> "<s values>" "<predict values>" [bench args]: the bench line per (s, predict)
     tag=$1; ss=$2; ps=$3; shift 3
     : > gpurun_out/r4/skin_sweep_$tag.jsonl

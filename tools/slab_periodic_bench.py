@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--native", action="store_true",
                     help="the library's own step driver (dsl_slab_wcsph_step): RCCL group send/recv to this same rank, "
                          "issued from C, periodic image shift in the append kernel")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="a library option (include/dslsph.h DSL_OPT_*)")
     a = ap.parse_args()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
@@ -109,6 +110,8 @@ def main():
     if a.no_exchange:
         drv.world = 1
     eng = drv.engine_core
+    for kv in a.opt:
+        eng.set_option(kv.split("=")[0], float(kv.split("=")[1]))
     drv.wcsph_step(a.warmup)
     eng.timing_reset()
     eng.timing_enable(not a.no_timing)
@@ -122,7 +125,7 @@ def main():
     st = drv.engine.status()
     stats = eng.stats()
     n_live, n_owned = eng.n, eng.n_owned()
-    out = {"ms_per_step": round(dt / a.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "owned": n_owned, "live_with_ghosts": n_live,
+    out = {"options": a.opt, "ms_per_step": round(dt / a.steps * 1e3, 4), "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 4), "owned": n_owned, "live_with_ghosts": n_live,
            "overlap": drv.overlap, "driver": "native" if a.native else ("python+rccl" if a.nccl else "python+copy"), "max_cell_count": stats.max_cell_count, "grid": list(stats.grid_dims), "status": st, "caps": [drv.engine.cap_full, drv.engine.cap_x],
            "message_MB": round(drv.engine.message_floats() * 4 / 1e6, 3) if not a.native else None,
            "kernels_ms_per_step": {k: round(eng.timing(k)[0] * eng.timing(k)[1] / a.steps, 4) for k in
