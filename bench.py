@@ -259,7 +259,12 @@ def main():
     dt = time.perf_counter() - t0
     skin1 = (engines[0].get_option("skin_steps"), engines[0].get_option("skin_rebuilds")) if world == 1 else (0, 0)
     skin_fields = (engines[0].get_option("skin_fields_own"), engines[0].get_option("skin_fields_padded")) if world == 1 else (0, 0)
-    skin_tau = engines[0].get_option("skin_tau_steps") if world == 1 else 0.0
+    def opt_or(name, default=0.0):  # (an older build loaded through DSL_LIB for an A/B run may not know the option)
+        try:
+            return engines[0].get_option(name)
+        except Exception:
+            return default
+    skin_tau = opt_or("skin_tau_steps") if world == 1 else 0.0
     if world > 1:
         dog.arm(limit, "per-kernel timing segment and the closing reductions")
     hot = {k: engines[0].timing(k) for k in ("density", "force_integrate", "pci_density")}
@@ -487,7 +492,7 @@ def main():
             "exact": exact,
             # DSL_OPT_SKIN: steps of the timed region that walked neighbour lists, and how many of them rebuilt the lists
             # (sort + candidate sweep) -- the region holds the share of rebuilds this phase of the flow asks for
-            "skin": {"s": eng.get_option("skin"), "predict": eng.get_option("skin_predict"), "tau_steps_last_rebuild": round(skin_tau, 2),
+            "skin": {"s": eng.get_option("skin"), "predict": opt_or("skin_predict"), "tau_steps_last_rebuild": round(skin_tau, 2),
                      "steps_in_timed_region": int(skin1[0] - skin0[0]),
                      "rebuilds_in_timed_region": int(skin1[1] - skin0[1]),
                      "list_overflow": int(eng.get_option("skin_list_overflow")),

@@ -599,9 +599,18 @@ int persistent_grid(const dsl_handle* h, int blocks_per_cu, bool lists = false) 
   // DSL_OPT_GRID_OVERSUB (default 8): eight times the workgroups the chip holds, each with an eighth of the share -- the
   // hardware hands them out as workgroups retire, which evens out tiles of unequal cost: developed flow density 0.96 ->
   // 0.89 ms, force 1.29 -> 1.24, lattice 0.64 -> 0.61 / 0.86 -> 0.83 (profiles/r04_grid_oversub.jsonl; 16 and 32: less)
-  // (not on slab ranks or small scenes: a rank of 16M / 8 -- 6k tiles -- measured 0.42 -> 0.43 ms per step with it)
-  const bool over = !lists && h->c.slab_axis < 0 && h->tg.ntiles >= 16384;
-  int g = 256 * blocks_per_cu * (over ? h->grid_oversub : 1);
+  // Never fewer than ~4 tiles per workgroup (a workgroup fetches its next tile's table and records under the current
+  // tile's sweep: with one tile each there is nothing to hide behind -- 4M PCISPH 2520 -> 2355 M particle-steps/s at 8x),
+  // and not on slab ranks (a rank of 16M / 8 measured 0.42 -> 0.43 ms per step).  The host knows the particle count, not
+  // the number of non-empty tiles: ~480 particles per tile.
+  // Measured: wins at 16M (+3.5 % lattice, +4 % developed) and 64M (+4 % PCISPH), loses at 4M (PCISPH 2530 -> 2410 even at
+  // 4 tiles per workgroup: every workgroup's first tile is fetched in the open) -- so only from 8M particles on.
+  int g = 256 * blocks_per_cu;
+  if (!lists && h->c.slab_axis < 0 && h->n >= 8000000) {
+    const long long by_tiles = (long long)h->n / (480 * 4);
+    const long long want = (long long)g * h->grid_oversub;
+    g = (int)std::max<long long>(g, std::min(want, by_tiles));
+  }
   // (tests: DSL_PERSISTENT_BLOCKS caps the grid, so that a small scene makes every workgroup walk MANY tiles -- the
   // tile-to-tile hand-over inside a workgroup is where the double-buffered loops can go wrong, and a test scene of a
   // few hundred tiles otherwise gives each workgroup one)

@@ -88,5 +88,20 @@ r=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=r['skin']
 print(json.dumps({'s': $s, 'predict': $p, 'value': r['value'], 'ms_per_step': r['ms_per_step'], 'rebuilds': k['rebuilds_in_timed_region'], 'tau_steps': k['tau_steps_last_rebuild'], 'fields_walked': k['fields_walked_per_particle'], 'density_ms': r['kernels_ms']['density'], 'force_ms': r['kernels_ms']['force_integrate'], 'suspensions': k['suspensions']}))" >> gpurun_out/r4/skin_sweep_$tag.jsonl || exit 1
       tail -1 gpurun_out/r4/skin_sweep_$tag.jsonl
     done; done; exit 0 ;;
+  final)        # tools/gpu_r04.sh final <tag>: the round's evidence on one box -- default bench line, kernel stats + PMC of the
+                # bench command, the other configurations' lines; summaries under gpurun_out/r4/final_<tag>/
+    tag=$1; out=gpurun_out/r4/final_$tag; mkdir -p $out
+    timeout -k 10 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "default bench rc=$?"
+    $0 prof $tag "k_force_list,k_density_list,k_list_build,k_density_pair,k_scatter,k_cell_rank" --steps 100 --warmup 20 > $out/prof.log 2>&1; echo "prof rc=$?"
+    cp -r gpurun_out/r4/prof_$tag/* $out/ 2>/dev/null
+    timeout -k 10 300 python bench.py --skin 0 --no-cpu-baseline --developed-steps 0 --exact-steps 0 > $out/wcsph_16m_plain_bench.json 2>/dev/null; echo "plain rc=$?"
+    timeout -k 10 300 python bench.py --n3 100 --steps 50 --warmup 10 --no-cpu-baseline --developed-steps 0 --exact-steps 0 > $out/wcsph_1m_bench.json 2>/dev/null; echo "1m rc=$?"
+    timeout -k 10 300 python bench.py --n3 400 --steps 20 --warmup 5 --no-cpu-baseline --developed-steps 0 --exact-steps 0 > $out/wcsph_64m_bench.json 2>/dev/null; echo "64m rc=$?"
+    timeout -k 10 400 python bench.py --method pcisph --n3 160 --steps 20 --warmup 5 --no-cpu-baseline > $out/pcisph_4m_bench.json 2>/dev/null; echo "pcisph 4m rc=$?"
+    timeout -k 10 600 python bench.py --method pcisph --n3 400 --extra-terms --steps 10 --warmup 3 --no-cpu-baseline --drift-steps 200 > $out/pcisph_64m_xsph_cohesion_bench.json 2>/dev/null; echo "pcisph 64m rc=$?"
+    for mode in "--native --nccl --no-timing" "--native --nccl --no-timing --no-overlap"; do
+      timeout -k 10 200 python tools/slab_periodic_bench.py $mode --steps 200 --warmup 20 2>/dev/null | grep "^{" >> $out/slab_runs.jsonl
+    done; echo "slab rc=$?"
+    python3 tools/benchline.py $out/*.json 2>/dev/null | cut -c1-220; exit 0 ;;
   *) echo "unknown: $what"; exit 2 ;;
 esac
