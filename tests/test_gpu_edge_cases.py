@@ -220,6 +220,19 @@ def test_full_size_16m_properties(n3):
     assert twin.get_option("skin_steps") == 0
     xs, vs, xt, vt = eng.download("positions"), eng.download("velocities"), twin.download("positions"), twin.download("velocities")
     twin.close()
+    # (d) DSL_OPT_GRID_OVERSUB (from 8M particles on the plain step's tile kernels are launched with 8 x the workgroups the
+    # chip holds): which workgroup sweeps a tile must not matter -- a second twin with persistent workgroups, same bits
+    if n >= 8000000:
+        twin1 = SPHEngine(p)
+        twin1.set_option("skin", 0.0)
+        twin1.set_option("grid_oversub", 1)
+        twin1.upload("positions", xb)
+        twin1.upload("velocities", vb)
+        twin1.reset_forces()
+        twin1.wcsph_step(4)
+        x1t, v1t = twin1.download("positions"), twin1.download("velocities")
+        twin1.close()
+        assert np.array_equal(x1t.view(np.uint32), xt.view(np.uint32)) and np.array_equal(v1t.view(np.uint32), vt.view(np.uint32))
     assert helpers.rel_err(xs, xt) < 2e-6
     assert np.abs(vs.astype(np.float64) - vt).max() < 2 * helpers.fast_velocity_tolerance(p, 4)
     assert eng.stats().steps == 8
