@@ -494,6 +494,18 @@ func (e *Engine) GetParams() (C.dsl_params, error) {
 	err := e.ck(C.dsl_get_params(e.h, &p))
 	return p, err
 }
+// Library options (DSL_OPT_* in include/dslsph.h) a host may want to name: the neighbour-list skin of WCSPHStep and its
+// read-only counters, how far ahead of the particles the lists are built, the tile kernels' grid oversubscription.
+const (
+	OptSkin            = int(C.DSL_OPT_SKIN)
+	OptSkinSteps       = int(C.DSL_OPT_SKIN_STEPS)
+	OptSkinRebuilds    = int(C.DSL_OPT_SKIN_REBUILDS)
+	OptSkinSuspensions = int(C.DSL_OPT_SKIN_SUSPENSIONS)
+	OptSkinPredict     = int(C.DSL_OPT_SKIN_PREDICT)
+	OptDeviceBytes     = int(C.DSL_OPT_DEVICE_BYTES)
+	OptGridOversub     = int(C.DSL_OPT_GRID_OVERSUB)
+)
+
 // SetOption / GetOption: library options (DSL_OPT_* in include/dslsph.h), e.g. the neighbour-list skin of WCSPHStep.
 func (e *Engine) SetOption(option int, value float64) error {
 	return e.ck(C.dsl_set_option(e.h, C.int(option), C.double(value)))
