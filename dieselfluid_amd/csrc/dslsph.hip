@@ -164,6 +164,10 @@ struct dsl_handle {
   float skin_predict = kSkinPredict;  // DSL_OPT_SKIN_PREDICT
   bool list_build_lockstep = true;    // DSL_OPT_LIST_BUILD
   int grid_oversub = 8;               // DSL_OPT_GRID_OVERSUB
+  // DSL_OPT_TILE_QUEUE: the single-domain tile kernels draw their tiles from per-XCD counters (kernels_tiled.hpp: TileFeed,
+  // dynamic mode) instead of walking a share dealt in advance.  16 launch sites x 16 ints, left at zero by every launch.
+  bool tile_queue = true;
+  int* walk_ctr = nullptr;
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
@@ -620,6 +624,15 @@ int persistent_grid(const dsl_handle* h, int blocks_per_cu, bool lists = false) 
   return g < 8 ? 8 : g;
 }
 
+// the tile queue's counters of one launch site (nullptr: the static walk); slab ranks keep the static walk -- their band and
+// interior launches overlap on two streams and walk lists other than list 0
+// (the density kernels keep the static walk: measured slower with the queue -- density walk 0.43 -> 0.55 ms for a register,
+// pair sweep of the developed flow 0.90 -> 0.98 -- where the force kernels gain 3-5 %: profiles/r04_tile_queue.jsonl)
+enum { kSiteForceList = 1, kSiteForceTiled = 3 };
+int* walk_ctr_of(const dsl_handle* h, int site) {
+  return (h->tile_queue && h->walk_ctr != nullptr && h->c.slab_axis < 0) ? h->walk_ctr + 16 * site : nullptr;
+}
+
 int density_pass(dsl_handle* h) {
   const DevConsts& c = h->c;
   CSoa3 p = cpos(h);
@@ -691,7 +704,8 @@ int force_integrate(dsl_handle* h, int part = 0) {
   int rc = DSL_OK;
   if (use_tiled(h)) {
     rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
-      int gsz = persistent_grid(h, 2);
+      int* wq = walk_ctr_of(h, kSiteForceTiled);
+      int gsz = persistent_grid(h, 2, wq != nullptr);
       // Two of these workgroups fill a CU's vector registers, and a persistent grid keeps them
       // filled until it ends: the band pack and the transfer kernels that are meant to run UNDER
       // the interior launch would not get a wave in before it is over (measured: a 7 us kernel
@@ -700,10 +714,13 @@ int force_integrate(dsl_handle* h, int part = 0) {
       if (part == 2 && gsz >= 64) gsz = (gsz - gsz / 8) & ~7;
       dim3 g(gsz), b(kTBlock);
 #define DSL_LAUNCH_FT4(GG, VV, XX, SS, HH)                                                                       \
-  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH>), g, b, 0, h->stream, c,      \
+  if (!(SS) && wq != nullptr) DSL_LAUNCH_FT5(GG, VV, XX, false, HH, true);                                       \
+  else DSL_LAUNCH_FT5(GG, VV, XX, SS, HH, false)
+#define DSL_LAUNCH_FT5(GG, VV, XX, SS, HH, QQ)                                                                   \
+  hipLaunchKernelGGL((k_force_integrate_tiled<GG, VV, kOutIntegrate, XX, SS, HH, false, QQ>), g, b, 0, h->stream, c, \
                      h->tg, tiles, n_tiles, gtiles, n_gtiles, h->tile_desc, h->cell_start, p, v, h->rho, h->pterm, f, uni,   \
                      po, vo, h->dstats, h->masks_valid ? h->nmask : nullptr, h->cap, ((XX) || (SS)) ? nullptr : h->n_tiles, bnd_of(h), \
-                     Soa3{nullptr, nullptr, nullptr})
+                     Soa3{nullptr, nullptr, nullptr}, wq)
   // (the XSPH / cohesion variant and the slab variant -- a slab always has half-empty ghost tiles -- exist
   // as the pass-sharing instantiation only; of the other two the device picks: kernels_tiled.hpp, share_wanted)
 #define DSL_LAUNCH_FT3(GG, VV, XX, SS)                                        \
@@ -729,6 +746,7 @@ int force_integrate(dsl_handle* h, int part = 0) {
       else if (G) DSL_LAUNCH_FT(true, false);
       else if (V) DSL_LAUNCH_FT(false, true);
       else DSL_LAUNCH_FT(false, false);
+#undef DSL_LAUNCH_FT5
 #undef DSL_LAUNCH_FT4
 #undef DSL_LAUNCH_FT3
 #undef DSL_LAUNCH_FT2
@@ -898,6 +916,7 @@ void free_all(dsl_handle* h) {
   if (h->pci_drift_host) (void)hipHostFree(h->pci_drift_host);
   if (h->ev_drift) (void)hipEventDestroy(h->ev_drift);
   (void)hipFree(h->skin_state);
+  (void)hipFree(h->walk_ctr);
   (void)hipFree(h->lists);
   for (int k = 0; k < 6; ++k) (void)hipFree(h->pvz[k]);
   for (int k = 0; k < 3; ++k) (void)hipFree(h->pvr[k]);
@@ -1076,6 +1095,7 @@ int dsl_create(const dsl_params* params, int device, dsl_handle** out) {
       (rc = dev_alloc(h, &h->cell_start, (size_t)h->ncell_pad)) ||
       (rc = dev_alloc(h, &h->block_sums, (size_t)h->nscan)) || (rc = dev_alloc(h, &h->stage, n * 3)) ||
       (rc = dev_alloc(h, &h->dstats, 1)) || (rc = dev_alloc(h, &h->dcounter, 8)) || (rc = dev_alloc(h, &h->dn, 16)) ||
+      (rc = dev_alloc(h, &h->walk_ctr, 256)) ||
       (rc = dev_alloc(h, &h->pack_counts, (size_t)4 * ((n + kPackChunk - 1) / kPackChunk))))
     return bail(rc);
   // the sort keeps these two clean between builds (k_scan_apply, k_tile_list)
@@ -1763,13 +1783,20 @@ int skin_step(dsl_handle* h) {
   const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
     dim3 g(persistent_grid(h, 2, true)), b(kLBlock);
-#define DSL_LAUNCH_FL(GG, VV)                                                                                             \
-  hipLaunchKernelGGL((k_force_list<GG, VV>), g, b, 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, h->tile_desc,       \
-                     h->cell_start, st, pX, vX, pZ, vZ, pR, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats)
+#define DSL_LAUNCH_FL2(GG, VV, QQ)                                                                                           \
+  hipLaunchKernelGGL((k_force_list<GG, VV, QQ>), g, b, 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, h->tile_desc,   \
+                     h->cell_start, st, pX, vX, pZ, vZ, pR, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats,        \
+                     walk_ctr_of(h, kSiteForceList))
+#define DSL_LAUNCH_FL(GG, VV)                                             \
+  do {                                                                    \
+    if (walk_ctr_of(h, kSiteForceList) != nullptr) DSL_LAUNCH_FL2(GG, VV, true); \
+    else DSL_LAUNCH_FL2(GG, VV, false);                                   \
+  } while (0)
     if (G && V) DSL_LAUNCH_FL(true, true);
     else if (G) DSL_LAUNCH_FL(true, false);
     else DSL_LAUNCH_FL(false, true);
 #undef DSL_LAUNCH_FL
+#undef DSL_LAUNCH_FL2
   });
   if (rc) return rc;
   h->cur_pv = Y;
@@ -1870,6 +1897,7 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
     case DSL_OPT_PCI_QPAIR: h->pci_qpair = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: h->pci_qrows = value != 0.0; return DSL_OK;
     case DSL_OPT_LIST_BUILD: h->list_build_lockstep = value != 0.0; return DSL_OK;
+    case DSL_OPT_TILE_QUEUE: h->tile_queue = value != 0.0; return DSL_OK;
     case DSL_OPT_GRID_OVERSUB:
       if (!(value >= 1.0 && value <= 64.0)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_GRID_OVERSUB is a factor in [1, 64]");
       h->grid_oversub = (int)value;
@@ -1912,6 +1940,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_PCI_QROWS: *value = h->pci_qrows ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_LIST_BUILD: *value = h->list_build_lockstep ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_GRID_OVERSUB: *value = (double)h->grid_oversub; return DSL_OK;
+    case DSL_OPT_TILE_QUEUE: *value = h->tile_queue ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_PCI_QINCR: *value = h->pci_qincr ? 1.0 : 0.0; return DSL_OK;
     default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
   }

@@ -491,6 +491,8 @@ __device__ __forceinline__ unsigned int shared_fields(const uint4* __restrict__ 
 // D over the lists: SPHField.Density (sph_field.go:155-172) + P/rho^2, FAST arithmetic -- the records, the test and
 // the sum are k_density_pair's, taken over the listed pairs only.
 // ---------------------------------------------------------------------------------
+// (walks its share of the tile list the static way: the tile queue's one register more -- thread 0's pending draw -- costs
+// this HBM-bound kernel its sixth wave per SIMD, 0.43 -> 0.55 ms; the force walk gains 5 % from the queue)
 __global__ __launch_bounds__(kLBlock, 4) void k_density_list(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                              const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                              const int* __restrict__ cell_start, const SkinState* st,
@@ -651,22 +653,23 @@ __global__ __launch_bounds__(kLBlock, 4) void k_density_list(DevConsts c, TileGr
 // per-pair operations, sph_field.go:175-200,251-269, fluid.go:175-197), walking list entries instead of mask bits.
 // Also tracks the step's max |v|^2 for the skin's displacement bound.
 // ---------------------------------------------------------------------------------
-template <bool WANT_G, bool WANT_V>
+template <bool WANT_G, bool WANT_V, bool QUEUE>
 __global__ __launch_bounds__(kLBlock, 4) void k_force_list(DevConsts c, TileGrid tg, const int* __restrict__ desc_of,
                                                            const int* __restrict__ n_tiles, const int* __restrict__ desc,
                                                            const int* __restrict__ cell_start, SkinState* st, CSoa3 pX,
                                                            CSoa3 vX, CSoa3 pZ, CSoa3 vZ, CSoa3 pR, const float* __restrict__ rho,
                                                            const float* __restrict__ pterm,
                                                            const uint4* __restrict__ lists, int lstride, Soa3 pout,
-                                                           Soa3 vout, DevStats* stats) {
+                                                           Soa3 vout, DevStats* stats, int* __restrict__ walk_ctr) {
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];  // x, y, z, P/rho^2
   __shared__ float4 B[kTCap];  // vx, vy, vz, 1/rho
+  __shared__ int feed_slot[2];
   const int tid = threadIdx.x;
   const bool rb = st->rebuild != 0;
   const CSoa3 pin = rb ? pZ : pX, vin = rb ? vZ : vX;
   unsigned int vbits = 0u, fbits = 0u, dbits = 0u;
-  TileFeed feed(desc_of, *n_tiles);
+  typename TileSource<QUEUE>::type feed = TileSource<QUEUE>::make(desc_of, *n_tiles, walk_ctr, feed_slot);
   int di = 0;
   bool have = feed.pop(di);
   if (have) tile_meta_store(metas[0], tile_meta_request(desc, di));
@@ -897,6 +900,7 @@ __global__ __launch_bounds__(kLBlock, 4) void k_force_list(DevConsts c, TileGrid
       vout.z[g] = vz;
     });
   }
+  feed.finish();
   wave_atomic_max(&stats->max_vel_bits, vbits);
   wave_atomic_max(&stats->max_f_bits, fbits);
   wave_atomic_max(&st->disp2_bits, dbits);

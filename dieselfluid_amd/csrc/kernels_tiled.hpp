@@ -533,6 +533,72 @@ struct TileFeed {
     if (have_next) next = desc_of ? desc_of[item] : item;
     return true;
   }
+  __device__ __forceinline__ void finish() {}
+};
+
+// The tile QUEUE (round 4; list 0 only, whose entries are their own descriptor indices): the tiles are not dealt in
+// advance -- every XCD has a counter, a workgroup takes the next position of its XCD's sequence when it starts a tile (the
+// same sequence the static walk deals out, so an XCD still works through one box of tiles at a time), and a workgroup
+// that drew cheap tiles simply takes more of them.  Thread 0 draws (one returning atomic, issued a whole tile before its
+// result is needed) and hands the position on through two LDS words, written before the barrier that precedes the pop
+// that reads them.  ctr[0..7]: the XCDs' counters, ctr[8]: workgroups that have finished -- the last one leaves all nine
+// at zero for the next launch (no memset between launches).  Same interface as TileFeed.
+struct TileQueue {
+  int* ctr;
+  int* slot;
+  int n, xcd, gs, k, pending;
+  __device__ __forceinline__ int item_of(int pos) const {
+    const int g = 1 << gs;
+    const int item = ((((pos >> gs) << 3) + xcd) << gs) + (pos & (g - 1));
+    return item < n ? item : -1;  // (positions map to ascending items: the first one past the list ends the sequence)
+  }
+  __device__ __forceinline__ TileQueue(int n_tiles, int* counters, int* lds_slot) : ctr(counters), slot(lds_slot), n(n_tiles), k(0), pending(0) {
+    const TileWalk w(n_tiles);
+    xcd = w.xcd;
+    gs = w.group_shift();
+    if (threadIdx.x == 0) {
+      slot[0] = item_of(atomicAdd(&ctr[xcd], 1));
+      pending = atomicAdd(&ctr[xcd], 1);
+    }
+    sync_lds();
+  }
+  __device__ __forceinline__ bool pop(int& desc_index) {
+    const int item = __builtin_amdgcn_readfirstlane(slot[k & 1]);  // (the same word for every lane: a scalar from here on)
+    if (threadIdx.x == 0) {
+      slot[(k + 1) & 1] = item_of(pending);  // (read after the next barrier; its last readers passed the previous one)
+      pending = atomicAdd(&ctr[xcd], 1);
+    }
+    k += 1;
+    if (item < 0) return false;
+    desc_index = item;
+    return true;
+  }
+  // at the end of the kernel (every thread calls it): the last workgroup to get here resets the counters.  A workgroup
+  // gets here only after a pop has told it that its XCD's sequence is exhausted, and its own draws have returned (the
+  // fence orders them before the count of finished workgroups).
+  __device__ __forceinline__ void finish() {
+    if (threadIdx.x != 0) return;
+    asm volatile("" ::"v"(pending) : "memory");
+    __threadfence();
+    if (atomicAdd(&ctr[8], 1) == (int)gridDim.x - 1) {
+      __threadfence();
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ctr[i] = 0;
+    }
+  }
+};
+// what a kernel instantiated with QUEUE walks its tile list with
+template <bool QUEUE>
+struct TileSource;
+template <>
+struct TileSource<false> {
+  using type = TileFeed;
+  static __device__ __forceinline__ TileFeed make(const int* __restrict__ desc_of, int n_tiles, int*, int*) { return TileFeed(desc_of, n_tiles); }
+};
+template <>
+struct TileSource<true> {
+  using type = TileQueue;
+  static __device__ __forceinline__ TileQueue make(const int* __restrict__, int n_tiles, int* ctr, int* slot) { return TileQueue(n_tiles, ctr, slot); }
 };
 
 // q = clamp(a*b + c, 0, 1) in ONE instruction (VOP3 clamp output modifier).  The kernel
@@ -1465,7 +1531,7 @@ constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2, kOutPci = 3;
 // z, y order, candidates ascending, one lane per target), IEEE sqrt and divide, bit for bit the oracle's
 // Gradient / LaplacianForce / Update; same staging, same masks (written by the EXACT density sweep).
 template <bool WANT_G, bool WANT_V, int OUT = kOutIntegrate, bool WANT_XS = false, bool SLAB = false, bool SHARE = true,
-          bool EXACT = false>
+          bool EXACT = false, bool QUEUE = false>
 // (Two 8-wave workgroups per CU need <= 128 VGPRs.  The headline instantiation gets there on its
 // own and schedules best unconstrained; the others are held to 4 waves/SIMD.)
 __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && !SHARE && !EXACT && OUT == kOutIntegrate) ? 1 : 4) void k_force_integrate_tiled(
@@ -1473,12 +1539,14 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int* __restrict__ ghost_desc_of, const int* __restrict__ n_ghost_tiles, const int* __restrict__ desc,
     const int* __restrict__ cell_start, CSoa3 pin, CSoa3 vin, const float* __restrict__ rho,
     const float* __restrict__ pterm, CSoa3 fin, int forces_uniform, Soa3 pout, Soa3 vout, DevStats* stats,
-    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd, Soa3 gout) {
+    const unsigned int* __restrict__ nmask, int mstride, const int* __restrict__ share_stats, Bnd bnd, Soa3 gout,
+    int* __restrict__ walk_ctr = nullptr) {
   static_assert(!(EXACT && SHARE), "the exact sums are sequential: one lane per target");
   if (share_stats != nullptr && share_wanted(share_stats) != SHARE) return;
   __shared__ TileMeta metas[2];
   __shared__ float4 A[kTCap];  // x,y,z,P/rho^2
   __shared__ float4 B[kTCap];  // vx,vy,vz,1/rho
+  __shared__ int feed_slot[2];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   unsigned int vbits = 0u, fbits = 0u;  // max|v|, max|F| of this lane over all its tiles
   // SLAB: after the tiles with owned cell layers, the ghost-only tiles (second list, walked the same
@@ -1488,7 +1556,8 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
   const int nphase = (SLAB && ghost_desc_of != nullptr) ? 2 : 1;
   for (int phase = 0; phase < nphase; ++phase) {
   const bool ghost_tile = phase == 1;
-  TileFeed feed(ghost_tile ? ghost_desc_of : desc_of, ghost_tile ? *n_ghost_tiles : *n_tiles);
+  static_assert(!(QUEUE && SLAB), "the tile queue walks list 0 of a single domain");
+  typename TileSource<QUEUE>::type feed = TileSource<QUEUE>::make(ghost_tile ? ghost_desc_of : desc_of, ghost_tile ? *n_ghost_tiles : *n_tiles, walk_ctr, feed_slot);
   // The NEXT tile's table (k_tile_desc) travels, one dword per lane, under the current tile's staging and
   // is put into the other LDS copy behind it: a tile starts with ONE barrier and its table in place.
   int di = 0;
@@ -2281,6 +2350,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
       }
     });
   }
+  feed.finish();
   }  // phase
   if constexpr (OUT == kOutIntegrate) {
     wave_atomic_max(&stats->max_vel_bits, vbits);

@@ -484,7 +484,7 @@ class SPHEngine:
     # library options (include/dslsph.h: DSL_OPT_*)
     OPTIONS = {"skin": 1, "skin_steps": 2, "skin_rebuilds": 3, "skin_list_overflow": 4, "skin_suspensions": 5, "device_bytes": 6, "skin_fields_own": 7, "skin_fields_padded": 8, "skin_predict": 9, "skin_tau_steps": 10,
                "density_pair": 16, "cell_keys": 17, "tile_box": 18, "persistent_blocks": 19, "pci_qtiled": 20,
-               "pci_qpair": 21, "pci_qrows": 22, "pci_qincr": 23, "list_build": 24, "grid_oversub": 25}
+               "pci_qpair": 21, "pci_qrows": 22, "pci_qincr": 23, "list_build": 24, "grid_oversub": 25, "tile_queue": 26}
 
     def set_option(self, name: str, value: float):
         self._ck(self._L.dsl_set_option(self._h, self.OPTIONS[name], float(value)))

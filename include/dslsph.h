@@ -437,12 +437,12 @@ int dsl_slab_wcsph_step(dsl_handle *h, int nsteps);
 int dsl_slab_pcisph_step(dsl_handle *h, int nsteps);
 
 /* Library options: behaviour that is the product's own and has no counterpart among the reference's parameters.
- *   DSL_OPT_SKIN (set/get): 0 = off, else a fraction s of h in (0, 0.2]; default 0.1 for DSL_MATH_FAST handles of at
- *       least two million particles, 0 otherwise.  dsl_wcsph_step (DSL_MATH_FAST, grid
+ *   DSL_OPT_SKIN (set/get): 0 = off, else a fraction s of h in (0, 0.2]; default 0.07 for DSL_MATH_FAST handles of at
+ *       least 200,000 particles, 0 otherwise.  dsl_wcsph_step (DSL_MATH_FAST, grid
  *       neighbours, single domain, no boundary particles) then keeps one neighbour LIST per particle, built against the
  *       cut-off h (1 + s) on cells h (1 + s) wide, and walks it step after step until some particle may have moved
- *       s h / 2 since the build -- measured on the device, by the integrating kernel, against the build's positions;
- *       only then does it sort and sweep again.  The sums are the reference's sums over { |x_i - x_j| < h }
+ *       s h / 2 since the build -- measured on the device, by the integrating kernel, against the build's reference
+ *       positions (DSL_OPT_SKIN_PREDICT); only then does it sort and sweep again.  The sums are the reference's sums over { |x_i - x_j| < h }
  *       (sph_field.go:155-200,251-269): a listed pair beyond h contributes exactly 0.  The reference itself rebuilds
  *       its sampler only every 4th CacheIncr (fluid.go:208-215).  DSL_MATH_EXACT rebuilds every step.
  *       Once the flow outruns the skin (five of the last 16 steps rebuilt -- a rebuild costs about two steps), or more
@@ -483,6 +483,9 @@ enum {
   DSL_OPT_GRID_OVERSUB = 25,      /* the tile kernels' grids are this many times the workgroups a chip holds at once (default 1:
                                      persistent workgroups, each walks its share of the tile list; k > 1: the hardware hands
                                      out k times as many, shorter shares as workgroups retire -- evens out tiles of unequal cost) */
+  DSL_OPT_TILE_QUEUE = 26,        /* 1 (default): the single-domain tile kernels draw their tiles from per-XCD counters as they go
+                                     (a workgroup that drew cheap tiles takes more of them); 0: every workgroup walks a share
+                                     dealt in advance (with DSL_OPT_GRID_OVERSUB shares on large scenes) */
   DSL_OPT_PCI_QINCR = 23          /* ... the rows kept from one correction iteration of a step to the next: only a query that
                                      has changed cells is moved (default 1; 0: every iteration fills the rows afresh) */
 };

@@ -198,9 +198,12 @@ def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method):
         p.eos_w = p.eos_w / 4
         p.delta = 1.0e-7
     res = []
-    for cap in (0, 8):
+    # (the third engine walks the tile list the static way -- every workgroup a share dealt in advance -- where the first
+    # two draw their tiles from the per-XCD counters of DSL_OPT_TILE_QUEUE)
+    for cap, queue in ((0, 1), (8, 1), (0, 0)):
         eng = SPHEngine(p, device=0)
         eng.set_option("persistent_blocks", cap)
+        eng.set_option("tile_queue", queue)
         eng.upload("positions", pos)
         eng.reset_forces()
         if method == "pcisph":
@@ -213,5 +216,6 @@ def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method):
         res.append((eng.download("positions"), eng.download("velocities"), eng.download("densities")))
         assert np.isfinite(res[-1][0]).all()
         eng.close()
-    for a, b in zip(res[0], res[1]):
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
