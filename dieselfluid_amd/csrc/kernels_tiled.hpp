@@ -484,6 +484,13 @@ __device__ __forceinline__ int b128_group_slot(int lane) {
 // group mostly hits its XCD's L2), round-robin, so that runs of cheap tiles -- ghost layers,
 // half-empty layers -- do not all land on one XCD.
 constexpr int kWalkGroupMax = 128;
+// groups in the whole list below which a group is not doubled again.  64 (groups of 128 tiles at 16M: 243 of them, 30 or 31
+// per XCD -- 3 % more work for three of the eight XCDs) until round 4; 512 (groups of 32: 121 or 122 per XCD) measured
+// +0.8 % on the bench line and +0.5 % on the developed flow in one call, 1024 / 2048 no better (profiles/r04_tile_groups.jsonl)
+#ifndef DSL_WALK_MIN_GROUPS
+#define DSL_WALK_MIN_GROUPS 512
+#endif
+constexpr int kWalkMinGroups = DSL_WALK_MIN_GROUPS;
 struct TileWalk {
   int li, lstep, xcd, n;  // (kept to four scalars: the kernels that use it are short of SGPRs)
   __device__ __forceinline__ TileWalk(int n_tiles) {
@@ -496,7 +503,7 @@ struct TileWalk {
   // (a short list dealt in big groups would leave some XCDs a whole group behind)
   __device__ __forceinline__ int group_shift() const {
     int s = 3;
-    while ((2 << s) <= kWalkGroupMax && (n >> (s + 1)) >= 64) ++s;
+    while ((2 << s) <= kWalkGroupMax && (n >> (s + 1)) >= kWalkMinGroups) ++s;
     return s;
   }
   __device__ __forceinline__ bool next(int& item) {
