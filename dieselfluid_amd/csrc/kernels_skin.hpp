@@ -70,10 +70,11 @@ __global__ void k_skin_decide(SkinState* st) {
   st->disp2_bits = 0u;
   st->vmax2_bits = 0u;
   st->n_steps += 1;
-  // a step that rebuilds costs 4.8 ms where a step that does not costs 1.5 and the plain step 2.0 to 2.8 (16M): from one
-  // rebuild in four or five steps on, the plain step is the faster one
+  // a rebuild adds 3.0 ms to a step that costs 1.5 where the plain step costs 1.9 (16M, end of round 4): lists pay while
+  // they live 7 steps or more -- three rebuilds in 16 steps are one too many (it was five while a rebuild cost 3.4 and the
+  // plain step 2.0 to 2.8)
   st->history = (st->history << 1) | (rb ? 1u : 0u);
-  if (st->n_steps >= 16 && __builtin_popcount(st->history & 0xffffu) >= 5) st->give_up = 1;
+  if (st->n_steps >= 16 && __builtin_popcount(st->history & 0xffffu) >= 3) st->give_up = 1;
 }
 
 // a tile's far-away record (the first pad record of staged row 0), as a list entry

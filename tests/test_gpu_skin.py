@@ -81,14 +81,15 @@ def test_skin_equals_plain_steps_to_tolerance_and_is_reproducible():
 def test_lists_built_at_predicted_positions_live_longer():
     """DSL_OPT_SKIN_PREDICT: a rebuild sorts, sweeps and lists at the REFERENCE positions x + tau v and displacement is
     measured against those, so the budget s h / 2 covers the way from -tau v to +tau v.  A block drifting at 0.01 h per
-    step (s = 0.1: 5 steps per build when built where the particles are) must need fewer rebuilds with the prediction
+    step (s = 0.1: 5 steps per build when built where the particles are; 30 steps: the library does not look at its
+    give-up flag before step 32) must need fewer rebuilds with the prediction
     than without, report its tau, and match the oracle -- which has no lists at all -- either way; two predicted runs
     agree bit for bit (tau is device state, a function of the simulation alone)."""
     n3 = 16
     p, pos, frc = _scene(n3)
     vel = np.zeros_like(pos)
     vel[:, 0] = 0.01 * p.h / p.dt
-    steps = 40
+    steps = 30
     ora = po.OracleSPH.from_state(helpers.oracle_params(p), pos, vel=vel, force=frc)
     ora.wcsph_step(steps)
     rebuilds, runs = {}, []
@@ -99,12 +100,13 @@ def test_lists_built_at_predicted_positions_live_longer():
         eng.wcsph_step(steps)
         tau = eng.get_option("skin_tau_steps")
         assert eng.get_option("skin_steps") == steps and eng.get_option("skin_list_overflow") == 0
+        assert eng.get_option("skin_suspensions") == 0
         rebuilds[predict] = eng.get_option("skin_rebuilds")
         assert (tau == 0.0) if predict == 0.0 else (2.0 < tau <= 16.0), tau  # 0.8 x 0.05 h / (0.01 h per step) = 4 steps
         _check(eng, ora, p, steps)
         runs.append((eng.download("positions"), eng.download("velocities")))
         eng.close()
-    assert 6 <= rebuilds[0.0] <= 12 and rebuilds[0.8] <= rebuilds[0.0] - 2, rebuilds
+    assert 5 <= rebuilds[0.0] <= 10 and rebuilds[0.8] <= rebuilds[0.0] - 2, rebuilds
     assert np.array_equal(runs[1][0].view(np.uint32), runs[2][0].view(np.uint32))
     assert np.array_equal(runs[1][1].view(np.uint32), runs[2][1].view(np.uint32))
     with pytest.raises(Exception):
