@@ -166,8 +166,9 @@ struct dsl_handle {
   int grid_oversub = 8;               // DSL_OPT_GRID_OVERSUB
   // DSL_OPT_TILE_QUEUE: the single-domain tile kernels draw their tiles from per-XCD counters (kernels_tiled.hpp: TileFeed,
   // dynamic mode) instead of walking a share dealt in advance.  16 launch sites x 16 ints, left at zero by every launch.
-  bool tile_queue = true;
+  int tile_queue = 1;  // 0 never, 1 from 8M particles on, 2 always (tests)
   int* walk_ctr = nullptr;
+  int walk_parity[16] = {};
   std::string err;
   SlabLink* link = nullptr;  // dsl_slab_attach: the slab's RCCL link to its neighbours (slab_link.hpp)
   // timing
@@ -629,8 +630,15 @@ int persistent_grid(const dsl_handle* h, int blocks_per_cu, bool lists = false) 
 // (the density kernels keep the static walk: measured slower with the queue -- density walk 0.43 -> 0.55 ms for a register,
 // pair sweep of the developed flow 0.90 -> 0.98 -- where the force kernels gain 3-5 %: profiles/r04_tile_queue.jsonl)
 enum { kSiteForceList = 1, kSiteForceTiled = 3 };
-int* walk_ctr_of(const dsl_handle* h, int site) {
-  return (h->tile_queue && h->walk_ctr != nullptr && h->c.slab_axis < 0) ? h->walk_ctr + 16 * site : nullptr;
+// (and only from 8M particles on, like the oversubscribed grids: with a handful of tiles per workgroup the draws are not
+// hidden -- 1M particles, 4 tiles per workgroup: force walk 0.063 -> 0.098 ms, profiles/r04_tile_queue_1m_4m.jsonl)
+int* walk_ctr_of(dsl_handle* h, int site) {
+  const bool on = h->tile_queue == 2 || (h->tile_queue == 1 && h->n >= 8000000);
+  if (!(on && h->walk_ctr != nullptr && h->c.slab_axis < 0)) return nullptr;
+  // a site's two blocks of eight counters are used alternately: a launch leaves the block it does not use at zero
+  // (kernels_tiled.hpp: TileQueue).  Called ONCE per step and site.
+  h->walk_parity[site] ^= 1;
+  return h->walk_ctr + 16 * site + 8 * h->walk_parity[site];
 }
 
 int density_pass(dsl_handle* h) {
@@ -1783,13 +1791,13 @@ int skin_step(dsl_handle* h) {
   const bool G = c.wcsph_pressure_force != 0, V = c.wcsph_viscosity != 0;
   rc = timed(h, DSL_K_FORCE_INTEGRATE, [&] {
     dim3 g(persistent_grid(h, 2, true)), b(kLBlock);
+    int* wql = walk_ctr_of(h, kSiteForceList);
 #define DSL_LAUNCH_FL2(GG, VV, QQ)                                                                                           \
   hipLaunchKernelGGL((k_force_list<GG, VV, QQ>), g, b, 0, h->stream, c, h->tg, h->tile_desc_of, h->n_tiles, h->tile_desc,   \
-                     h->cell_start, st, pX, vX, pZ, vZ, pR, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats,        \
-                     walk_ctr_of(h, kSiteForceList))
+                     h->cell_start, st, pX, vX, pZ, vZ, pR, h->rho, h->pterm, h->lists, h->cap, po, vo, h->dstats, wql)
 #define DSL_LAUNCH_FL(GG, VV)                                             \
   do {                                                                    \
-    if (walk_ctr_of(h, kSiteForceList) != nullptr) DSL_LAUNCH_FL2(GG, VV, true); \
+    if (wql != nullptr) DSL_LAUNCH_FL2(GG, VV, true);                     \
     else DSL_LAUNCH_FL2(GG, VV, false);                                   \
   } while (0)
     if (G && V) DSL_LAUNCH_FL(true, true);
@@ -1897,7 +1905,10 @@ int dsl_set_option(dsl_handle* h, int option, double value) {
     case DSL_OPT_PCI_QPAIR: h->pci_qpair = value != 0.0; return DSL_OK;
     case DSL_OPT_PCI_QROWS: h->pci_qrows = value != 0.0; return DSL_OK;
     case DSL_OPT_LIST_BUILD: h->list_build_lockstep = value != 0.0; return DSL_OK;
-    case DSL_OPT_TILE_QUEUE: h->tile_queue = value != 0.0; return DSL_OK;
+    case DSL_OPT_TILE_QUEUE:
+      if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_TILE_QUEUE is 0, 1 or 2");
+      h->tile_queue = (int)value;
+      return DSL_OK;
     case DSL_OPT_GRID_OVERSUB:
       if (!(value >= 1.0 && value <= 64.0)) return fail(h, DSL_ERR_INVALID, "dsl_set_option: DSL_OPT_GRID_OVERSUB is a factor in [1, 64]");
       h->grid_oversub = (int)value;
@@ -1940,7 +1951,7 @@ int dsl_get_option(dsl_handle* h, int option, double* value) {
     case DSL_OPT_PCI_QROWS: *value = h->pci_qrows ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_LIST_BUILD: *value = h->list_build_lockstep ? 1.0 : 0.0; return DSL_OK;
     case DSL_OPT_GRID_OVERSUB: *value = (double)h->grid_oversub; return DSL_OK;
-    case DSL_OPT_TILE_QUEUE: *value = h->tile_queue ? 1.0 : 0.0; return DSL_OK;
+    case DSL_OPT_TILE_QUEUE: *value = (double)h->tile_queue; return DSL_OK;
     case DSL_OPT_PCI_QINCR: *value = h->pci_qincr ? 1.0 : 0.0; return DSL_OK;
     default: return fail(h, DSL_ERR_INVALID, "dsl_get_option: unknown option");
   }

@@ -546,26 +546,33 @@ struct TileFeed {
 // The tile QUEUE (round 4; list 0 only, whose entries are their own descriptor indices): the tiles are not dealt in
 // advance -- every XCD has a counter, a workgroup takes the next position of its XCD's sequence when it starts a tile (the
 // same sequence the static walk deals out, so an XCD still works through one box of tiles at a time), and a workgroup
-// that drew cheap tiles simply takes more of them.  Thread 0 draws (one returning atomic, issued a whole tile before its
-// result is needed) and hands the position on through two LDS words, written before the barrier that precedes the pop
-// that reads them.  ctr[0..7]: the XCDs' counters, ctr[8]: workgroups that have finished -- the last one leaves all nine
-// at zero for the next launch (no memset between launches).  Same interface as TileFeed.
+// that drew cheap tiles simply takes more of them.  A workgroup's FIRST tile is the static walk's (position blockIdx / 8
+// of its XCD's sequence: no draw, nothing to wait for at the start -- 512 workgroups drawing from eight addresses at once
+// cost a 1M-particle launch a third of its time); the counters hand out the positions behind those.  Thread 0 draws (one
+// returning atomic, issued a whole tile before its result is needed) and hands the position on through two LDS words,
+// written before the barrier that precedes the pop that reads them.  A launch site owns TWO blocks of eight counters and
+// uses them alternately (the host flips): a launch zeroes the block it does NOT use, which is the one the next launch
+// will -- no memset, and no count of finished workgroups, between launches.  Same interface as TileFeed.
 struct TileQueue {
   int* ctr;
   int* slot;
-  int n, xcd, gs, k, pending;
+  int n, xcd, gs, k, pending, first;
   __device__ __forceinline__ int item_of(int pos) const {
     const int g = 1 << gs;
     const int item = ((((pos >> gs) << 3) + xcd) << gs) + (pos & (g - 1));
     return item < n ? item : -1;  // (positions map to ascending items: the first one past the list ends the sequence)
   }
-  __device__ __forceinline__ TileQueue(int n_tiles, int* counters, int* lds_slot) : ctr(counters), slot(lds_slot), n(n_tiles), k(0), pending(0) {
+  // `counters`: this launch's block of 8; `other`: the block to leave at zero for the next launch
+  __device__ __forceinline__ TileQueue(int n_tiles, int* counters, int* other, int* lds_slot)
+      : ctr(counters), slot(lds_slot), n(n_tiles), k(0), pending(0) {
     const TileWalk w(n_tiles);
     xcd = w.xcd;
     gs = w.group_shift();
+    first = (int)(gridDim.x + 7 - xcd) >> 3;  // workgroups on this XCD: their first tiles are positions 0 .. first - 1
+    if (blockIdx.x == 0 && threadIdx.x < 8) other[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
-      slot[0] = item_of(atomicAdd(&ctr[xcd], 1));
-      pending = atomicAdd(&ctr[xcd], 1);
+      slot[0] = item_of((int)(blockIdx.x >> 3));
+      pending = first + atomicAdd(&ctr[xcd], 1);
     }
     sync_lds();
   }
@@ -573,26 +580,14 @@ struct TileQueue {
     const int item = __builtin_amdgcn_readfirstlane(slot[k & 1]);  // (the same word for every lane: a scalar from here on)
     if (threadIdx.x == 0) {
       slot[(k + 1) & 1] = item_of(pending);  // (read after the next barrier; its last readers passed the previous one)
-      pending = atomicAdd(&ctr[xcd], 1);
+      pending = first + atomicAdd(&ctr[xcd], 1);
     }
     k += 1;
     if (item < 0) return false;
     desc_index = item;
     return true;
   }
-  // at the end of the kernel (every thread calls it): the last workgroup to get here resets the counters.  A workgroup
-  // gets here only after a pop has told it that its XCD's sequence is exhausted, and its own draws have returned (the
-  // fence orders them before the count of finished workgroups).
-  __device__ __forceinline__ void finish() {
-    if (threadIdx.x != 0) return;
-    asm volatile("" ::"v"(pending) : "memory");
-    __threadfence();
-    if (atomicAdd(&ctr[8], 1) == (int)gridDim.x - 1) {
-      __threadfence();
-#pragma unroll
-      for (int i = 0; i < 9; ++i) ctr[i] = 0;
-    }
-  }
+  __device__ __forceinline__ void finish() {}
 };
 // what a kernel instantiated with QUEUE walks its tile list with
 template <bool QUEUE>
@@ -605,7 +600,12 @@ struct TileSource<false> {
 template <>
 struct TileSource<true> {
   using type = TileQueue;
-  static __device__ __forceinline__ TileQueue make(const int* __restrict__, int n_tiles, int* ctr, int* slot) { return TileQueue(n_tiles, ctr, slot); }
+  // (`ctr`: this launch's block of 8 counters.  A launch site owns two blocks, 32 bytes each, the pair 64-byte aligned --
+  // dslsph.hip: walk_ctr_of -- so the other block is found from the address)
+  static __device__ __forceinline__ TileQueue make(const int* __restrict__, int n_tiles, int* ctr, int* slot) {
+    const bool upper = ((reinterpret_cast<unsigned long long>(ctr) >> 5) & 1ull) != 0ull;  // blocks are 32 bytes, pairs 64-byte aligned
+    return TileQueue(n_tiles, ctr, upper ? ctr - 8 : ctr + 8, slot);
+  }
 };
 
 // q = clamp(a*b + c, 0, 1) in ONE instruction (VOP3 clamp output modifier).  The kernel

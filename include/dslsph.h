@@ -483,9 +483,9 @@ enum {
   DSL_OPT_GRID_OVERSUB = 25,      /* the tile kernels' grids are this many times the workgroups a chip holds at once (default 1:
                                      persistent workgroups, each walks its share of the tile list; k > 1: the hardware hands
                                      out k times as many, shorter shares as workgroups retire -- evens out tiles of unequal cost) */
-  DSL_OPT_TILE_QUEUE = 26,        /* 1 (default): the single-domain tile kernels draw their tiles from per-XCD counters as they go
-                                     (a workgroup that drew cheap tiles takes more of them); 0: every workgroup walks a share
-                                     dealt in advance (with DSL_OPT_GRID_OVERSUB shares on large scenes) */
+  DSL_OPT_TILE_QUEUE = 26,        /* the two force kernels of a single domain draw their tiles from per-XCD counters as they go (a
+                                     workgroup that drew cheap tiles takes more of them) instead of walking a share dealt in
+                                     advance: 1 (default) from 8M particles on, 2 always, 0 never */
   DSL_OPT_PCI_QINCR = 23          /* ... the rows kept from one correction iteration of a step to the next: only a query that
                                      has changed cells is moved (default 1; 0: every iteration fills the rows afresh) */
 };

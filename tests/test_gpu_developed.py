@@ -199,8 +199,8 @@ def test_results_do_not_depend_on_how_tiles_are_dealt_to_workgroups(method):
         p.delta = 1.0e-7
     res = []
     # (the third engine walks the tile list the static way -- every workgroup a share dealt in advance -- where the first
-    # two draw their tiles from the per-XCD counters of DSL_OPT_TILE_QUEUE)
-    for cap, queue in ((0, 1), (8, 1), (0, 0)):
+    # two draw their tiles from the per-XCD counters of DSL_OPT_TILE_QUEUE: 2 = at any size)
+    for cap, queue in ((0, 2), (8, 2), (0, 0)):
         eng = SPHEngine(p, device=0)
         eng.set_option("persistent_blocks", cap)
         eng.set_option("tile_queue", queue)
