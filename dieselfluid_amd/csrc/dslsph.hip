@@ -1659,7 +1659,7 @@ namespace {
 // ---------------------------------------------------------------------------------------
 // the skin step (kernels_skin.hpp): neighbour lists that live for several steps
 // ---------------------------------------------------------------------------------------
-// Every kSkinLook skin steps the host reads one word of the device state: has the flow outrun the skin (three of the last
+// Every kSkinLook skin steps the host reads one word of the device state: has the flow outrun the skin (five of the last
 // 16 steps rebuilt)?  Then the lists cost more than they save and the step goes back to sorting and sweeping every step
 // for kSkinRetry steps.  Both happen at step counts fixed in advance: results do not depend on timing or on how the
 // steps were grouped into calls.

@@ -70,11 +70,13 @@ __global__ void k_skin_decide(SkinState* st) {
   st->disp2_bits = 0u;
   st->vmax2_bits = 0u;
   st->n_steps += 1;
-  // a rebuild adds 3.0 ms to a step that costs 1.5 where the plain step costs 1.9 (16M, end of round 4): lists pay while
-  // they live 7 steps or more -- three rebuilds in 16 steps are one too many (it was five while a rebuild cost 3.4 and the
-  // plain step 2.0 to 2.8)
+  // a rebuild adds 3.1 ms to a step that costs 1.4 where the plain step costs 1.9 (16M, end of round 4): lists pay while
+  // they live 6-7 steps or more.  The library gives up later than that, at five rebuilds in 16 steps: a suspension lasts
+  // thousands of steps, and the first steps of a run -- the lattice's jitter relaxing -- rebuild two or three times as often
+  // as the hundreds that follow (with three in 16 a skin of 0.065 was suspended at step 32 of the bench scene and the run
+  // lost 17 %: profiles/r04_skin_sweep_final.jsonl)
   st->history = (st->history << 1) | (rb ? 1u : 0u);
-  if (st->n_steps >= 16 && __builtin_popcount(st->history & 0xffffu) >= 3) st->give_up = 1;
+  if (st->n_steps >= 16 && __builtin_popcount(st->history & 0xffffu) >= 5) st->give_up = 1;
 }
 
 // a tile's far-away record (the first pad record of staged row 0), as a list entry

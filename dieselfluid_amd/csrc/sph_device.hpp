@@ -108,7 +108,7 @@ struct SkinState {
   float budget;     // s h / 2, less a rounding margin
   float dt;
   unsigned int history;  // bit k: the step k steps ago rebuilt
-  int give_up;      // three of the last 16 steps rebuilt: the flow outruns the skin, the lists no longer pay (host: suspend)
+  int give_up;      // five of the last 16 steps rebuilt: the flow outruns the skin, the lists no longer pay (host: suspend)
   int unlisted;     // targets of the last rebuild that got no list (tiles beyond the LDS budget): they take the global-memory sweep
   int n_live;       // particles
   // of the last rebuild: list fields the targets need, and fields they hold once padded to their wave's longest list

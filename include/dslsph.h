@@ -445,7 +445,7 @@ int dsl_slab_pcisph_step(dsl_handle *h, int nsteps);
  *       positions (DSL_OPT_SKIN_PREDICT); only then does it sort and sweep again.  The sums are the reference's sums over { |x_i - x_j| < h }
  *       (sph_field.go:155-200,251-269): a listed pair beyond h contributes exactly 0.  The reference itself rebuilds
  *       its sampler only every 4th CacheIncr (fluid.go:208-215).  DSL_MATH_EXACT rebuilds every step.
- *       Once the flow outruns the skin (three of the last 16 steps rebuilt -- a rebuild costs about two steps: lists pay while they live 7 steps or more), or more
+ *       Once the flow outruns the skin (five of the last 16 steps rebuilt -- a rebuild costs about two steps), or more
  *       than one particle in 64 sits in a tile whose wider cells no longer fit the LDS image, the library suspends it by
  *       itself for the next 2048 steps (twice as long after every suspension in a row, up to 32768), then tries again; it looks every 32 steps, at step counts
  *       fixed in advance, so results never depend on timing.
