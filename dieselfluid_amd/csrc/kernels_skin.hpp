@@ -13,11 +13,14 @@
 //     the grid a tile is 4 x 4 x 3 cells (TileGrid::tbz): with cells h (1 + s) wide that is the ~512 targets and ~1900
 //     staged records of the plain step's 4 x 4 x 4 tile, so one 8-wave workgroup walks a tile with every wave busy
 //     and two of them share a CU's LDS, as in the plain step's kernels;
-//   * a list is valid while no particle has moved further than s h / 2 since the build: every pair closer than h now
-//     was closer than h (1 + s) then.  That displacement is measured ON THE DEVICE (k_force_list: |x - x_build|, the
-//     build's positions being the sort's output set, which the steps in between never overwrite) and k_skin_decide, the
-//     first kernel of every step, turns its maximum into the step's `rebuild` flag; the kernels of the rebuild chain are launched every step and return at once
-//     while the flag is down.  No host round trip, and the decision is a function of the simulation state alone;
+//   * a list is valid while no particle is further than s h / 2 from the REFERENCE position its list was built at:
+//     every pair closer than h now had references closer than h (1 + s).  The reference is x + tau v -- where the particle
+//     will be about half way through the lists' life (SkinState::tau, chosen by k_skin_decide at every rebuild; any
+//     reference is sound) -- written out in sorted order by the build's scatter and never overwritten between rebuilds.
+//     The displacement is measured ON THE DEVICE (k_force_list: |x - reference|) and k_skin_decide, the first kernel of
+//     every step, turns its maximum into the step's `rebuild` flag; the kernels of the rebuild chain are launched every
+//     step and return at once while the flag is down.  No host round trip, and the decision is a function of the
+//     simulation state alone;
 //   * between rebuilds a step is two kernels: k_density_list (sph_field.go:155-172 over the list: 7 VALU
 //     instructions per LISTED pair where the sweep spends 7 per CANDIDATE, 216 of them) and k_force_list (the fused
 //     gradient + viscosity + Update walk: one v_and / v_lshr per pair where the mask walk spends six on bit
@@ -43,8 +46,8 @@ constexpr int kLQuads = 14;                 // staging: quads of 4 records per r
 static_assert(kTRows * kLQuads <= kLBlock, "one quad per lane");
 
 // first kernel of every skin step: this step's rebuild flag.  The lists are good for the positions the previous step
-// left if no particle is further than s h / 2 from where it was when they were built; k_force_list measures exactly that
-// (the sort's output set, which no step overwrites, IS the build's positions).
+// left if no particle is further than s h / 2 from the reference position its list was built at; k_force_list measures
+// exactly that (the references sit in sorted order in a set of their own, which no step overwrites).
 __global__ void k_skin_decide(SkinState* st) {
   const float d = __builtin_sqrtf(__uint_as_float(st->disp2_bits)) * (1.0f + 1.0e-6f);
   const bool rb = st->force != 0 || !(d <= st->budget);
