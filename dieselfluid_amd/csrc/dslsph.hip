@@ -635,6 +635,10 @@ enum { kSiteForceList = 1, kSiteForceTiled = 3 };
 int* walk_ctr_of(dsl_handle* h, int site) {
   const bool on = h->tile_queue == 2 || (h->tile_queue == 1 && h->n >= 8000000);
   if (!(on && h->walk_ctr != nullptr && h->c.slab_axis < 0)) return nullptr;
+  // (a host that is capturing this stream into a graph of its own gets the static walk: a replayed launch would find the
+  // counter block its captured twin left behind, not the zeroed one -- the two blocks alternate per LAUNCH CALL)
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return nullptr;
   // a site's two blocks of eight counters are used alternately: a launch leaves the block it does not use at zero
   // (kernels_tiled.hpp: TileQueue).  Called ONCE per step and site.
   h->walk_parity[site] ^= 1;

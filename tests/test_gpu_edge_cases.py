@@ -371,3 +371,40 @@ def test_a_box_eight_times_taller_and_no_budget_for_side_arrays(math_mode):
     assert res[1][2] < res[0][2]  # the side arrays are really not there
     if math_mode == 0:
         assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+
+
+def test_steps_captured_into_a_host_graph_replay_to_the_same_bits():
+    """A host may capture the engine's launches into a graph of its own (dsl_set_stream + stream capture) and replay it.
+    Two plain steps are the unit that can be replayed (the position / velocity sets and the slot maps ping-pong per
+    step on the host side).  The tile queue (DSL_OPT_TILE_QUEUE) alternates between two counter blocks per LAUNCH CALL,
+    which a replay does not repeat -- so a capturing stream gets the static walk -- and two replays of the captured pair
+    must equal four steps taken directly, bit for bit (FAST results do not depend on how tiles are dealt)."""
+    import torch
+    from dieselfluid_amd import SPHEngine, scenes
+    n3 = 32
+    p, pos = scenes.dambreak_scene(n3, math_mode=FAST)
+    out = []
+    for captured in (False, True):
+        eng = SPHEngine(p, device=0)
+        eng.set_option("skin", 0.0)
+        eng.set_option("tile_queue", 2)
+        eng.upload("positions", pos)
+        eng.reset_forces()
+        eng.wcsph_step(2)  # (allocations and first-use paths out of the way)
+        if captured:
+            s = torch.cuda.Stream()
+            eng.sync()
+            eng.set_stream(s.cuda_stream)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                eng.wcsph_step(2)
+            g.replay()
+            g.replay()
+            torch.cuda.synchronize()
+            eng.use_own_stream()
+        else:
+            eng.wcsph_step(4)
+        out.append((eng.download("positions"), eng.download("velocities")))
+        eng.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
