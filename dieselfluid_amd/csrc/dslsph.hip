@@ -491,11 +491,11 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   h->build_seq = h->build_seq == INT_MAX ? 1 : h->build_seq + 1;  // (never 0: the flag word starts zeroed)
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
     if (h->pci_active)
-      hipLaunchKernelGGL(k_cell_rank<true>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
+      hipLaunchKernelGGL(k_cell_rank<true>, dim3(grid_for((n + kRankUnroll - 1) / kRankUnroll)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                          ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
                          nullptr, nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3, h->dcounter + 4, h->build_seq);
     else
-      hipLaunchKernelGGL(k_cell_rank<false>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
+      hipLaunchKernelGGL(k_cell_rank<false>, dim3(grid_for((n + kRankUnroll - 1) / kRankUnroll)), dim3(kBlock), 0, h->stream, c, p.x, p.y, p.z,
                          ordered ? h->ids[h->cur_ids] : nullptr, h->rank, h->cell_count, h->unordered,
                          nullptr, nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0);
   });
@@ -535,7 +535,10 @@ int build_grid(dsl_handle* h, bool carry_derived) {
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work),
                   want_dest ? h->rank : nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter<false>, dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
+    if (a.nf == 6)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<false, 6>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<false, kMaxScatter>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
     if (ordered)  // (with key rows: the flag-gated fallback for cells of more than kCellKeys particles, a small grid)
       hipLaunchKernelGGL(k_scatter_ordered, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
                          h->stream, c, a, so, p, h->rank, h->cell_start);
@@ -1732,7 +1735,7 @@ int skin_step(dsl_handle* h) {
   HIP_TRY(h, hipGetLastError());
   // the rebuild chain: launched every step, every kernel returns at once unless this step rebuilds
   int rc = timed(h, DSL_K_CELL_RANK, [&] {
-    hipLaunchKernelGGL((k_cell_rank<false, true>), dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, pX.x, pX.y, pX.z,
+    hipLaunchKernelGGL((k_cell_rank<false, true>), dim3(std::min(grid_for((n + kRankUnroll - 1) / kRankUnroll), 4096)), dim3(kBlock), 0, h->stream, c, pX.x, pX.y, pX.z,
                        ordered ? h->ids[0] : nullptr, h->rank, h->cell_count, h->unordered, nullptr, nullptr,
                        ordered ? h->cell_keys : nullptr, h->dcounter + 3, nullptr, 0, gate, h->ids[1], vX);
   });
@@ -1755,7 +1758,7 @@ int skin_step(dsl_handle* h) {
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work), nullptr,
                   ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter<true>, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate,
+    hipLaunchKernelGGL(k_scatter_chain<true>, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate,
                        vX, pRw);
     if (ordered)
       hipLaunchKernelGGL(k_scatter_ordered<true>, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,

@@ -21,6 +21,7 @@ constexpr int kBlock = 256;
 // 288 GB), touched only where particles are.  A cell with more members than a row holds falls back to the two-pass
 // form (k_scatter_ordered), launched as a small flag-gated grid.
 constexpr int kCellKeys = 32;
+constexpr int kRankUnroll = 2;  // particles per lane and trip of k_cell_rank
 constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lanes x int4
 
 // ---------------------------------------------------------------------------------
@@ -74,48 +75,79 @@ __global__ __launch_bounds__(kBlock) void k_cell_rank(DevConsts c, const float* 
   const int n = live_n(c);
   // (grid-stride: the skin step launches a capped grid -- on the steps that do not rebuild, all a launch does is find
   // its gate closed, and 62,500 workgroups doing that took 14 us; every other caller's grid covers n in one trip)
-  for (int first = blockIdx.x * kBlock; first < n; first += gridDim.x * kBlock) {
-  const int i = first + threadIdx.x;
-  int cell = -1, id = 0;
-  if (i < n) {
-    if constexpr (REF) cell = sort_cell(c, skin_ref(px[i], vel.x[i], tau), skin_ref(py[i], vel.y[i], tau), skin_ref(pz[i], vel.z[i], tau));
-    else cell = sort_cell(c, px[i], py[i], pz[i]);
-    if (ids) id = ids[i];
+  // A workgroup takes kRankUnroll x kBlock consecutive particles per trip, a lane one of each sub-block: the loads of
+  // all sub-blocks are in flight together, and so are their atomics -- the kernel is two dependent round trips
+  // (position -> cell -> returning atomic -> rank) with next to no arithmetic, and one particle per lane left the
+  // memory pipe idle between them (0.144 ms for 24 B x 16M particles: 2.7 TB/s).
+  for (int first = blockIdx.x * (kRankUnroll * kBlock); first < n; first += gridDim.x * (kRankUnroll * kBlock)) {
+  int cell[kRankUnroll], id[kRankUnroll], head_lane[kRankUnroll], base[kRankUnroll];
+  bool mark[kRankUnroll];
+  // (loads without a branch around them -- a lane past the end reads the last particle and forgets it -- so that the
+  // compiler issues all of them before the first wait)
+  float x[kRankUnroll], y[kRankUnroll], z[kRankUnroll];
+#pragma unroll
+  for (int u = 0; u < kRankUnroll; ++u) {
+    const int i = min(first + u * kBlock + (int)threadIdx.x, n - 1);
+    x[u] = px[i];
+    y[u] = py[i];
+    z[u] = pz[i];
+    if constexpr (REF) {
+      x[u] = skin_ref(x[u], vel.x[i], tau);
+      y[u] = skin_ref(y[u], vel.y[i], tau);
+      z[u] = skin_ref(z[u], vel.z[i], tau);
+    }
+    id[u] = ids ? ids[i] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < kRankUnroll; ++u) {
+    const bool in = first + u * kBlock + (int)threadIdx.x < n;
+    cell[u] = in ? sort_cell(c, x[u], y[u], z[u]) : -1;
+    if (!in) id[u] = 0;
     // PCISPH (OFF_GRID; the flag is never cleared: it holds the number of the last build that saw such a particle): does any particle lie outside the
     // grid's bounds, clamped into an outermost cell by the cell rule?  (false for NaN: that particle is nobody's neighbour)
     if constexpr (OFF_GRID) {
       bool off = false;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float f = floorf(((a == 0 ? px[i] : (a == 1 ? py[i] : pz[i])) - c.gmin[a]) * c.inv_cell);
+        const float f = floorf(((a == 0 ? x[u] : (a == 1 ? y[u] : z[u])) - c.gmin[a]) * c.inv_cell);
         off |= f < 0.0f || f >= (float)c.dims[a];
       }
-      if (off) *off_grid = build_seq;  // (benign race: every writer stores the same number)
+      if (in && off) *off_grid = build_seq;  // (benign race: every writer stores the same number)
     }
   }
-  const int prev = __shfl_up(cell, 1, kWave), prev_id = __shfl_up(id, 1, kWave);
-  const bool head = (lane == 0) || (cell != prev);
-  const unsigned long long heads = __ballot(head);
-  // lanes that break the ascending-id order of their run (ids == nullptr: nobody asks for an order)
-  const unsigned long long breaks = __ballot(ids != nullptr && !head && id <= prev_id);
-  const unsigned long long le = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-  const int head_lane = 63 - __builtin_clzll(le);  // le always has bit 0 set
-  const unsigned long long above = (head_lane == 63) ? 0ull : (heads & ~((2ull << head_lane) - 1ull));
-  const int next = above ? __builtin_ctzll(above) : kWave;
-  const int run = next - head_lane;
-  int base = 0;
-  // (a whole band of stale ghosts would otherwise hammer one counter: same-address atomics serialise)
-  if (lane == head_lane && cell >= 0 && cell != c.ncell) {
-    base = atomicAdd(&cell_count[cell], run);
-    const unsigned long long mine = (next == kWave ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << head_lane) - 1ull);
-    if (ids != nullptr && (base != 0 || (breaks & mine) != 0ull)) atomicOr(&unordered[cell >> 5], 1u << (cell & 31));
+  unsigned long long run_mask[kRankUnroll];
+#pragma unroll
+  for (int u = 0; u < kRankUnroll; ++u) {
+    const int prev = __shfl_up(cell[u], 1, kWave), prev_id = __shfl_up(id[u], 1, kWave);
+    const bool head = (lane == 0) || (cell[u] != prev);
+    const unsigned long long heads = __ballot(head);
+    // lanes that break the ascending-id order of their run (ids == nullptr: nobody asks for an order)
+    const unsigned long long breaks = __ballot(ids != nullptr && !head && id[u] <= prev_id);
+    const unsigned long long le = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    head_lane[u] = 63 - __builtin_clzll(le);  // le always has bit 0 set
+    const unsigned long long above = (head_lane[u] == 63) ? 0ull : (heads & ~((2ull << head_lane[u]) - 1ull));
+    const int next = above ? __builtin_ctzll(above) : kWave;
+    const int run = next - head_lane[u];
+    base[u] = 0;
+    const unsigned long long mine = (next == kWave ? ~0ull : ((1ull << next) - 1ull)) & ~((1ull << head_lane[u]) - 1ull);
+    run_mask[u] = breaks & mine;
+    // (a whole band of stale ghosts would otherwise hammer one counter: same-address atomics serialise)
+    mark[u] = lane == head_lane[u] && cell[u] >= 0 && cell[u] != c.ncell;
+    if (mark[u]) base[u] = atomicAdd(&cell_count[cell[u]], run);
   }
-  base = __shfl(base, head_lane, kWave);
-  const int r = base + (lane - head_lane);
-  if (i < n) rank[i] = r;  // (the scatter recomputes the cell: cheaper than 8 B of traffic)
-  if (cell_keys != nullptr && i < n && cell >= 0 && cell != c.ncell) {
-    if (r < kCellKeys) cell_keys[(size_t)cell * kCellKeys + r] = id;
-    else *overfull = 1;  // (rare: benign race, every writer stores 1)
+  // (the atomics of all sub-blocks are in flight; their results are looked at only now)
+#pragma unroll
+  for (int u = 0; u < kRankUnroll; ++u)
+    if (mark[u] && ids != nullptr && (base[u] != 0 || run_mask[u] != 0ull)) atomicOr(&unordered[cell[u] >> 5], 1u << (cell[u] & 31));
+#pragma unroll
+  for (int u = 0; u < kRankUnroll; ++u) {
+    const int i = first + u * kBlock + threadIdx.x;
+    const int r = __shfl(base[u], head_lane[u], kWave) + (lane - head_lane[u]);
+    if (i < n) rank[i] = r;  // (the scatter recomputes the cell: cheaper than 8 B of traffic)
+    if (cell_keys != nullptr && i < n && cell[u] >= 0 && cell[u] != c.ncell) {
+      if (r < kCellKeys) cell_keys[(size_t)cell[u] * kCellKeys + r] = id[u];
+      else *overfull = 1;  // (rare: benign race, every writer stores 1)
+    }
   }
   }
 }
@@ -290,8 +322,103 @@ __device__ __forceinline__ ScatterIds skin_ids(const ScatterArrays& a, const Ski
   if (gate.st != nullptr && gate.st->ids_sel == 0) return ScatterIds{a.ids_dst, const_cast<int*>(a.ids_src)};  // 1 -> 0
   return ScatterIds{a.ids_src, a.ids_dst};
 }
-template <bool REF = false>
+// The scatter is a chain of dependent memory round trips -- position -> cell -> cell_start -> key row -> stores --
+// and with one particle per lane nothing but other waves covers them.  Everything that does not depend on the cell
+// (the payload of every array, the id, the rank) is therefore requested up front, together with the position, and
+// everything that depends on the cell alone (both ends of its slot range, its word of the `unordered` bitmap) in one
+// second batch; the stores go out last, back to back.  (The first form moved the arrays in a loop of load -> wait ->
+// store, one array at a time over pointers fetched from the kernel arguments inside the loop: 10 serial round
+// trips per particle, 0.39 ms for the developed 16M flow at 30 % of the HBM roof.)
+// NFMAX: 6 = positions and velocities only (every WCSPH build; no per-array test), kMaxScatter = any a.nf.
+template <int NFMAX>
+struct ScatterPayload {
+  float v[NFMAX];
+};
+template <int NFMAX>
+__device__ __forceinline__ void scatter_fetch(const ScatterArrays& a, int i, ScatterPayload<NFMAX>& p) {
+#pragma unroll
+  for (int f = 0; f < NFMAX; ++f) {
+    p.v[f] = 0.0f;
+    if (NFMAX == 6 || f < a.nf) p.v[f] = a.src[f][i];
+  }
+}
+template <bool REF, int NFMAX>
+__device__ __forceinline__ void scatter_store(const ScatterArrays& a, const ScatterOrder& o, int i, int d, int id,
+                                              int* __restrict__ ids_dst, const Soa3& ref, const SortPos& sp,
+                                              const ScatterPayload<NFMAX>& p) {
+  ids_dst[d] = id;
+#pragma unroll
+  for (int f = 0; f < NFMAX; ++f)
+    if (NFMAX == 6 || f < a.nf) a.dst[f][d] = p.v[f];
+  if constexpr (REF) {  // (skin step: the reference positions in sorted order -- what the lists are built at)
+    ref.x[d] = sp.x;
+    ref.y[d] = sp.y;
+    ref.z[d] = sp.z;
+  }
+  if (o.dest) o.dest[i] = d;
+}
+
+template <bool REF = false, int NFMAX = kMaxScatter>
 __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
+                                                    const int* __restrict__ rank,
+                                                    const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr},
+                                                    CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},
+                                                    Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
+  if (gate.closed()) return;
+  const ScatterIds ids = skin_ids(a, gate);
+  const float tau = REF ? gate.st->tau : 0.0f;
+  const int n = live_n(c);
+  // the sort's positions (and, skin step, velocities) are the first arrays of the payload in every caller: read once
+  const bool pos_in_payload = a.nf >= (REF ? 6 : 3) && pos.x == a.src[0] && pos.y == a.src[1] && pos.z == a.src[2] &&
+                              (!REF || (vel.x == a.src[3] && vel.y == a.src[4] && vel.z == a.src[5]));
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {  // (grid-stride: see k_cell_rank)
+  bool later = false;
+  ScatterPayload<NFMAX> pay;
+  scatter_fetch<NFMAX>(a, i, pay);
+  const int id = ids.src[i], r = rank[i];
+  SortPos sp;
+  if (pos_in_payload) {
+    if constexpr (REF) sp = SortPos{skin_ref(pay.v[0], pay.v[3], tau), skin_ref(pay.v[1], pay.v[4], tau), skin_ref(pay.v[2], pay.v[5], tau)};
+    else sp = SortPos{pay.v[0], pay.v[1], pay.v[2]};
+  } else {
+    sp = sort_pos<REF>(pos, vel, tau, i);
+  }
+  const int cell = sort_cell(c, sp.x, sp.y, sp.z);
+  if (cell != c.ncell) {  // (a stale ghost is dropped)
+    const int s = cell_start[cell], e = cell_start[cell + 1];
+    const unsigned int uword = o.unordered != nullptr ? o.unordered[cell >> 5] : 0u;
+    int d = s + r;
+    later = ((uword >> (cell & 31)) & 1u) != 0u;
+    if (later && o.cell_keys != nullptr) {
+      const int cnt = e - s;
+      if (cnt <= kCellKeys) {  // the common case: the cell's ids are in its key row, count the smaller ones
+        const int4* row = reinterpret_cast<const int4*>(o.cell_keys + (size_t)cell * kCellKeys);
+        int below = 0;
+        for (int k0 = 0; k0 < cnt; k0 += 8) {  // eight ids per trip (a cell holds ~8)
+          const int4 u = row[k0 / 4], w = row[k0 / 4 + 1];
+          const int key[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            below += (k0 + q < cnt && (key[q] < id || (key[q] == id && k0 + q < r))) ? 1 : 0;
+        }
+        d = s + below;
+        later = false;
+      }
+    }
+    if (later) o.keys[d] = id;
+    else scatter_store<REF, NFMAX>(a, o, i, d, id, ids.dst, ref, sp, pay);
+  }
+  if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later ? 1 : 0;
+  }
+}
+
+// The skin step's sort (REF: cells of the reference positions x + tau v, a capped grid that strides over the particles
+// because on most steps all a launch does is find its gate closed) keeps the first form of the scatter, one array at a
+// time: the batched form above, instantiated with REF and walked in more than one trip, rebuilt on every step of
+// tests/test_gpu_skin.py (displacements against garbage references) for a reason the ISA did not give away in the time
+// there was; a rebuild is 6 steps in 100 and the scatter a tenth of it.
+template <bool REF = true>
+__global__ __launch_bounds__(kBlock) void k_scatter_chain(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr},
                                                     CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},

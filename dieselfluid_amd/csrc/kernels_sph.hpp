@@ -667,7 +667,21 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
   unsigned int err_bits = 0u;
   float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
   // (the particle's own position is only read where something asks for it: slab ownership, the drift statistic)
-  if (i < live_n(c) && !bnd.is(i) && (GHOSTS || c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i]))) {
+  // Everything the kernel reads per particle is requested BEFORE its first store: pp, pv and frc are written below, and
+  // a load behind those stores (the position for the drift statistic, the query's slot of the previous iteration) has
+  // to wait for them -- one more round trip each, in a kernel that is nothing but round trips.
+  const bool want_pos = drift != nullptr || c.slab_axis >= 0;
+  float opx = 0.f, opy = 0.f, opz = 0.f;
+  int old_slot = -1;
+  if (i < live_n(c)) {
+    if (want_pos) {
+      opx = p.x[i];
+      opy = p.y[i];
+      opz = p.z[i];
+    }
+    if constexpr (INCR) old_slot = qslot[i];
+  }
+  if (i < live_n(c) && !bnd.is(i) && (GHOSTS || c.slab_axis < 0 || slab_owned(c, opx, opy, opz))) {
     const float fx = frc.x[i], fy = frc.y[i], fz = frc.z[i];
     const float ax = fx * c.inv_mass, ay = fy * c.inv_mass, az = fz * c.inv_mass;
     const float dvx = ax * c.dt, dvy = ay * c.dt, dvz = az * c.dt;
@@ -686,8 +700,8 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
       frc.z[i] = fz + gterm.z[i];
     }
     mine = true;
-    if (drift != nullptr) left = pci_left_tile(c, p.x[i], p.y[i], p.z[i], qx, qy, qz);
-    if (c.slab_axis >= 0 && (!GHOSTS || slab_owned(c, p.x[i], p.y[i], p.z[i])) && pci_query_escaped(c, qx, qy, qz))
+    if (drift != nullptr) left = pci_left_tile(c, opx, opy, opz, qx, qy, qz);
+    if (c.slab_axis >= 0 && (!GHOSTS || slab_owned(c, opx, opy, opz)) && pci_query_escaped(c, qx, qy, qz))
       stats->pci_escaped = 1;
     bool far = false;
     if (all_inside) {
@@ -701,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
       const float density_error = c.W0 - c.ref_density;
       const float abs_err = dsl_div<FAST>(density_error, c.ref_density);
       press[i] += density_error * c.delta;
-      if (!GHOSTS || c.slab_axis < 0 || slab_owned(c, p.x[i], p.y[i], p.z[i])) err_bits = nonneg_bits(abs_err);
+      if (!GHOSTS || c.slab_axis < 0 || slab_owned(c, opx, opy, opz)) err_bits = nonneg_bits(abs_err);
     } else {
       cell = cell_of(c, qx, qy, qz);
       rec = make_float4(qx, qy, qz, __int_as_float(i));
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void k_pci_predict_bin(DevConsts c, Bnd bnd
   // words of a 16 MB histogram are ~120 us of this kernel, about what that many random 64-byte accesses cost.
   if constexpr (INCR) {
     if (i < live_n(c)) {
-      const int old = qslot[i];
+      const int old = old_slot;
       if (old >= 0 && old / row_slots == cell) {
         qrows[old] = rec;
       } else {
