@@ -536,9 +536,9 @@ int build_grid(dsl_handle* h, bool carry_derived) {
                   want_dest ? h->rank : nullptr, ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
     if (a.nf == 6)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<false, 6>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<false, 6>), dim3(grid_for((n + kScatterUnroll - 1) / kScatterUnroll)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<false, kMaxScatter>), dim3(grid_for(n)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<false, kMaxScatter>), dim3(grid_for((n + kScatterUnroll - 1) / kScatterUnroll)), dim3(kBlock), 0, h->stream, c, a, so, p, h->rank, h->cell_start);
     if (ordered)  // (with key rows: the flag-gated fallback for cells of more than kCellKeys particles, a small grid)
       hipLaunchKernelGGL(k_scatter_ordered, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,
                          h->stream, c, a, so, p, h->rank, h->cell_start);

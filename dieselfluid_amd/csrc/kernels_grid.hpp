@@ -21,7 +21,10 @@ constexpr int kBlock = 256;
 // 288 GB), touched only where particles are.  A cell with more members than a row holds falls back to the two-pass
 // form (k_scatter_ordered), launched as a small flag-gated grid.
 constexpr int kCellKeys = 32;
-constexpr int kRankUnroll = 2;  // particles per lane and trip of k_cell_rank
+#ifndef DSL_RANK_UNROLL
+#define DSL_RANK_UNROLL 2
+#endif
+constexpr int kRankUnroll = DSL_RANK_UNROLL;  // particles per lane and trip of k_cell_rank
 constexpr int kScanTile = 4096;  // cells per scan block: 4 sub-tiles of 256 lanes x int4
 
 // ---------------------------------------------------------------------------------
@@ -358,57 +361,83 @@ __device__ __forceinline__ void scatter_store(const ScatterArrays& a, const Scat
   if (o.dest) o.dest[i] = d;
 }
 
+// kScatterUnroll particles per lane (i, i + kBlock, ...): twice the loads in flight per wave for the same chain.
+#ifndef DSL_SCATTER_UNROLL
+#define DSL_SCATTER_UNROLL 2
+#endif
+constexpr int kScatterUnroll = DSL_SCATTER_UNROLL;
 template <bool REF = false, int NFMAX = kMaxScatter>
 __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
                                                     const int* __restrict__ rank,
                                                     const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr},
                                                     CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},
                                                     Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
+  static_assert(!REF, "the skin step's sort uses k_scatter_chain (below)");
+  constexpr int U = kScatterUnroll;
   if (gate.closed()) return;
   const ScatterIds ids = skin_ids(a, gate);
-  const float tau = REF ? gate.st->tau : 0.0f;
   const int n = live_n(c);
-  // the sort's positions (and, skin step, velocities) are the first arrays of the payload in every caller: read once
-  const bool pos_in_payload = a.nf >= (REF ? 6 : 3) && pos.x == a.src[0] && pos.y == a.src[1] && pos.z == a.src[2] &&
-                              (!REF || (vel.x == a.src[3] && vel.y == a.src[4] && vel.z == a.src[5]));
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {  // (grid-stride: see k_cell_rank)
-  bool later = false;
-  ScatterPayload<NFMAX> pay;
-  scatter_fetch<NFMAX>(a, i, pay);
-  const int id = ids.src[i], r = rank[i];
-  SortPos sp;
-  if (pos_in_payload) {
-    if constexpr (REF) sp = SortPos{skin_ref(pay.v[0], pay.v[3], tau), skin_ref(pay.v[1], pay.v[4], tau), skin_ref(pay.v[2], pay.v[5], tau)};
-    else sp = SortPos{pay.v[0], pay.v[1], pay.v[2]};
-  } else {
-    sp = sort_pos<REF>(pos, vel, tau, i);
+  // the sort's positions are the first arrays of the payload in every caller: read once
+  const bool pos_in_payload = a.nf >= 3 && pos.x == a.src[0] && pos.y == a.src[1] && pos.z == a.src[2];
+  const int first = blockIdx.x * (U * kBlock) + threadIdx.x;  // (one trip: the grid covers n / U particles)
+  if (first >= n) return;
+  ScatterPayload<NFMAX> pay[U];
+  int id[U], r[U], cell[U], s[U], e[U], d[U];
+  unsigned int uword[U];
+  SortPos sp[U];
+  bool in[U], later[U];
+  // batch 1: everything that does not depend on the cell (a lane past the end reads the last particle and drops it)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    in[u] = first + u * kBlock < n;
+    const int i = min(first + u * kBlock, n - 1);
+    scatter_fetch<NFMAX>(a, i, pay[u]);
+    id[u] = ids.src[i];
+    r[u] = rank[i];
+    if (pos_in_payload) sp[u] = SortPos{pay[u].v[0], pay[u].v[1], pay[u].v[2]};
+    else sp[u] = sort_pos<false>(pos, vel, 0.0f, i);
   }
-  const int cell = sort_cell(c, sp.x, sp.y, sp.z);
-  if (cell != c.ncell) {  // (a stale ghost is dropped)
-    const int s = cell_start[cell], e = cell_start[cell + 1];
-    const unsigned int uword = o.unordered != nullptr ? o.unordered[cell >> 5] : 0u;
-    int d = s + r;
-    later = ((uword >> (cell & 31)) & 1u) != 0u;
-    if (later && o.cell_keys != nullptr) {
-      const int cnt = e - s;
+  // batch 2: what depends on the cell alone
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    cell[u] = sort_cell(c, sp[u].x, sp[u].y, sp[u].z);
+    const int cc = min(cell[u], c.ncell - 1);  // (a stale ghost -- pseudo cell ncell -- reads the last cell and is dropped)
+    s[u] = cell_start[cc];
+    e[u] = cell_start[cc + 1];
+    uword[u] = o.unordered != nullptr ? o.unordered[cc >> 5] : 0u;
+  }
+  // the slot: the atomic rank, or -- a cell whose order the sort has to establish -- the number of smaller ids in the
+  // cell's key row
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    d[u] = s[u] + r[u];
+    later[u] = in[u] && cell[u] != c.ncell && ((uword[u] >> (cell[u] & 31)) & 1u) != 0u;
+    if (later[u] && o.cell_keys != nullptr) {
+      const int cnt = e[u] - s[u];
       if (cnt <= kCellKeys) {  // the common case: the cell's ids are in its key row, count the smaller ones
-        const int4* row = reinterpret_cast<const int4*>(o.cell_keys + (size_t)cell * kCellKeys);
+        const int4* row = reinterpret_cast<const int4*>(o.cell_keys + (size_t)cell[u] * kCellKeys);
         int below = 0;
         for (int k0 = 0; k0 < cnt; k0 += 8) {  // eight ids per trip (a cell holds ~8)
-          const int4 u = row[k0 / 4], w = row[k0 / 4 + 1];
-          const int key[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+          const int4 v = row[k0 / 4], w = row[k0 / 4 + 1];
+          const int key[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
 #pragma unroll
           for (int q = 0; q < 8; ++q)
-            below += (k0 + q < cnt && (key[q] < id || (key[q] == id && k0 + q < r))) ? 1 : 0;
+            below += (k0 + q < cnt && (key[q] < id[u] || (key[q] == id[u] && k0 + q < r[u]))) ? 1 : 0;
         }
-        d = s + below;
-        later = false;
+        d[u] = s[u] + below;
+        later[u] = false;
       }
     }
-    if (later) o.keys[d] = id;
-    else scatter_store<REF, NFMAX>(a, o, i, d, id, ids.dst, ref, sp, pay);
   }
-  if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later ? 1 : 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = first + u * kBlock;
+    if (!in[u]) continue;
+    if (cell[u] != c.ncell) {  // (a stale ghost is dropped)
+      if (later[u]) o.keys[d[u]] = id[u];
+      else scatter_store<false, NFMAX>(a, o, i, d[u], id[u], ids.dst, ref, sp[u], pay[u]);
+    }
+    if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later[u] ? 1 : 0;
   }
 }
 
