@@ -1758,7 +1758,7 @@ int skin_step(dsl_handle* h) {
   ScatterOrder so{ordered ? h->unordered : nullptr, h->sort_keys, reinterpret_cast<unsigned char*>(h->sort_work), nullptr,
                   ordered ? h->cell_keys : nullptr, h->dcounter + 3};
   rc = timed(h, DSL_K_SCATTER, [&] {
-    hipLaunchKernelGGL(k_scatter_chain<true>, dim3(std::min(grid_for(n), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter<true, 6>), dim3(std::min(grid_for((n + kScatterUnroll - 1) / kScatterUnroll), 4096)), dim3(kBlock), 0, h->stream, c, a, so, pX, h->rank, h->cell_start, gate,
                        vX, pRw);
     if (ordered)
       hipLaunchKernelGGL(k_scatter_ordered<true>, dim3(h->cell_keys ? std::min(grid_for(n), 1024) : grid_for(n)), dim3(kBlock), 0,

@@ -331,7 +331,7 @@ __device__ __forceinline__ ScatterIds skin_ids(const ScatterArrays& a, const Ski
 // everything that depends on the cell alone (both ends of its slot range, its word of the `unordered` bitmap) in one
 // second batch; the stores go out last, back to back.  (The first form moved the arrays in a loop of load -> wait ->
 // store, one array at a time over pointers fetched from the kernel arguments inside the loop: 10 serial round
-// trips per particle, 0.39 ms for the developed 16M flow at 30 % of the HBM roof.)
+// trips per particle, 0.39 ms for the developed 16M flow at 30 % of the HBM roof; now 0.23.)
 // NFMAX: 6 = positions and velocities only (every WCSPH build; no per-array test), kMaxScatter = any a.nf.
 template <int NFMAX>
 struct ScatterPayload {
@@ -372,15 +372,21 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
                                                     const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr},
                                                     CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},
                                                     Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
-  static_assert(!REF, "the skin step's sort uses k_scatter_chain (below)");
   constexpr int U = kScatterUnroll;
   if (gate.closed()) return;
-  const ScatterIds ids = skin_ids(a, gate);
+  // (the two id maps by two selects on one flag -- NOT through skin_ids(): in this kernel hipcc 7.2 hoisted that
+  // function's swap of the two pointers above its test of ids_sel and swapped them on BOTH paths -- s_mov pairs in front
+  // of the s_cmp in the ISA -- so that every second rebuild read the wrong map; tests/test_gpu_skin.py fails on it at once)
+  const bool swap_ids = gate.st != nullptr && gate.st->ids_sel == 0;
+  const int* ids_src = swap_ids ? a.ids_dst : a.ids_src;
+  int* ids_dst = swap_ids ? const_cast<int*>(a.ids_src) : a.ids_dst;
+  const float tau = REF ? gate.st->tau : 0.0f;
   const int n = live_n(c);
-  // the sort's positions are the first arrays of the payload in every caller: read once
-  const bool pos_in_payload = a.nf >= 3 && pos.x == a.src[0] && pos.y == a.src[1] && pos.z == a.src[2];
-  const int first = blockIdx.x * (U * kBlock) + threadIdx.x;  // (one trip: the grid covers n / U particles)
-  if (first >= n) return;
+  // the sort's positions (skin step: and velocities) are the first arrays of the payload in every caller: read once
+  const bool pos_in_payload = a.nf >= (REF ? 6 : 3) && pos.x == a.src[0] && pos.y == a.src[1] && pos.z == a.src[2] &&
+                              (!REF || (vel.x == a.src[3] && vel.y == a.src[4] && vel.z == a.src[5]));
+  // (grid-stride: the skin step launches a capped grid, see k_cell_rank; every other caller's grid covers n / U in one trip)
+  for (int first = blockIdx.x * (U * kBlock) + threadIdx.x; first < n; first += gridDim.x * (U * kBlock)) {
   ScatterPayload<NFMAX> pay[U];
   int id[U], r[U], cell[U], s[U], e[U], d[U];
   unsigned int uword[U];
@@ -392,10 +398,14 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
     in[u] = first + u * kBlock < n;
     const int i = min(first + u * kBlock, n - 1);
     scatter_fetch<NFMAX>(a, i, pay[u]);
-    id[u] = ids.src[i];
+    id[u] = ids_src[i];
     r[u] = rank[i];
-    if (pos_in_payload) sp[u] = SortPos{pay[u].v[0], pay[u].v[1], pay[u].v[2]};
-    else sp[u] = sort_pos<false>(pos, vel, 0.0f, i);
+    if (pos_in_payload) {
+      if constexpr (REF) sp[u] = SortPos{skin_ref(pay[u].v[0], pay[u].v[3], tau), skin_ref(pay[u].v[1], pay[u].v[4], tau), skin_ref(pay[u].v[2], pay[u].v[5], tau)};
+      else sp[u] = SortPos{pay[u].v[0], pay[u].v[1], pay[u].v[2]};
+    } else {
+      sp[u] = sort_pos<REF>(pos, vel, tau, i);
+    }
   }
   // batch 2: what depends on the cell alone
 #pragma unroll
@@ -435,56 +445,10 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
     if (!in[u]) continue;
     if (cell[u] != c.ncell) {  // (a stale ghost is dropped)
       if (later[u]) o.keys[d[u]] = id[u];
-      else scatter_store<false, NFMAX>(a, o, i, d[u], id[u], ids.dst, ref, sp[u], pay[u]);
+      else scatter_store<REF, NFMAX>(a, o, i, d[u], id[u], ids_dst, ref, sp[u], pay[u]);
     }
     if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later[u] ? 1 : 0;
   }
-}
-
-// The skin step's sort (REF: cells of the reference positions x + tau v, a capped grid that strides over the particles
-// because on most steps all a launch does is find its gate closed) keeps the first form of the scatter, one array at a
-// time: the batched form above, instantiated with REF and walked in more than one trip, rebuilt on every step of
-// tests/test_gpu_skin.py (displacements against garbage references) for a reason the ISA did not give away in the time
-// there was; a rebuild is 6 steps in 100 and the scatter a tenth of it.
-template <bool REF = true>
-__global__ __launch_bounds__(kBlock) void k_scatter_chain(DevConsts c, ScatterArrays a, ScatterOrder o, CSoa3 pos,
-                                                    const int* __restrict__ rank,
-                                                    const int* __restrict__ cell_start, SkinGate gate = SkinGate{nullptr},
-                                                    CSoa3 vel = CSoa3{nullptr, nullptr, nullptr},
-                                                    Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
-  if (gate.closed()) return;
-  const ScatterIds ids = skin_ids(a, gate);
-  const float tau = REF ? gate.st->tau : 0.0f;
-  const int n = live_n(c);
-  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {  // (grid-stride: see k_cell_rank)
-  bool later = false;
-  const SortPos sp = sort_pos<REF>(pos, vel, tau, i);
-  const int cell = sort_cell(c, sp.x, sp.y, sp.z);
-  if (cell != c.ncell) {  // (a stale ghost is dropped)
-    const int id = ids.src[i];
-    const int s = cell_start[cell], r = rank[i];
-    int d = s + r;
-    later = o.unordered != nullptr && ((o.unordered[cell >> 5] >> (cell & 31)) & 1u);
-    if (later && o.cell_keys != nullptr) {
-      const int cnt = cell_start[cell + 1] - s;
-      if (cnt <= kCellKeys) {  // the common case: the cell's ids are in its key row, count the smaller ones
-        const int4* row = reinterpret_cast<const int4*>(o.cell_keys + (size_t)cell * kCellKeys);
-        int below = 0;
-        for (int k0 = 0; k0 < cnt; k0 += 8) {  // eight ids per trip (a cell holds ~8)
-          const int4 u = row[k0 / 4], w = row[k0 / 4 + 1];
-          const int key[8] = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            below += (k0 + q < cnt && (key[q] < id || (key[q] == id && k0 + q < r))) ? 1 : 0;
-        }
-        d = s + below;
-        later = false;
-      }
-    }
-    if (later) o.keys[d] = id;
-    else scatter_move<REF>(a, o, i, d, id, ids.dst, ref, sp);
-  }
-  if (o.unordered != nullptr && o.cell_keys == nullptr) o.later[i] = later ? 1 : 0;
   }
 }
 

@@ -740,7 +740,19 @@ __device__ __forceinline__ bool share_wanted(const int* __restrict__ stats) {
 // SHARE = false compiles the full passes only (every pass one lane per target): the instantiation
 // for a scene whose tiles hold exactly kTBlock targets (a lattice at rest) is a few per cent faster
 // without the second copy of the body; the host picks per step from the tile statistics.
-template <bool SHARE, int BLOCK = kTBlock, class Body>
+// NINE: a remainder of more than BLOCK / 16 targets -- too many for sixteen lanes each -- is shared out NINE lanes to a
+// target, seven groups per wave (lane 63 idles), one run per lane: body(true_type, t, sub, 9), whose sums the body
+// combines itself over the group's lanes (nine_lane_sum).  With powers of two the developed flow's pair sweep (281 slots
+// per tile on 256 lanes: 25 left) gave each of them eight lanes, i.e. TWO runs for lane 0 -- the pass takes as long as its
+// busiest lane -- where nine lanes take one.
+__device__ __forceinline__ float nine_lane_sum(float v) {
+  const int g0 = ((threadIdx.x & (kWave - 1)) / 9) * 9;
+  float s = __shfl(v, g0, kWave);
+#pragma unroll
+  for (int j = 1; j < 9; ++j) s += __shfl(v, g0 + j, kWave);
+  return s;
+}
+template <bool SHARE, int BLOCK = kTBlock, bool NINE = false, class Body>
 __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, Body&& body) {
   int tbase = 0;
   for (; SHARE ? ntarg - tbase > BLOCK / 2 : tbase < ntarg; tbase += BLOCK) {
@@ -750,6 +762,16 @@ __device__ __forceinline__ void for_each_target(int ntarg, int tid, int tperm, B
   if constexpr (SHARE)
   while (tbase < ntarg) {
     const int rem = ntarg - tbase;
+    if constexpr (NINE) {
+      constexpr int kGroups = (BLOCK / kWave) * 7;  // nine-lane groups per block
+      if (rem > BLOCK / 16 && rem <= 2 * kGroups) {
+        const int lane = tid & (kWave - 1);
+        const int t = (tid / kWave) * 7 + lane / 9;
+        if (lane < 63 && t < rem) body(std::true_type{}, tbase + t, lane % 9, 9);
+        tbase += min(rem, kGroups);
+        continue;
+      }
+    }
     const int shift = rem > BLOCK / 4 ? 1 : (rem > BLOCK / 8 ? 2 : (rem > BLOCK / 16 ? 3 : 4));  // 16: one run per lane
     const int t = tid >> shift;
     if (t < rem) body(std::true_type{}, tbase + t, tid & ((1 << shift) - 1), 1 << shift);
@@ -1246,6 +1268,10 @@ __global__ __launch_bounds__(kTBlock, 4) void k_density_tiled(DevConsts c, TileG
 // same q, same masks, same sums in the same order per target as k_density_tiled<.., false>: the results are the same bits.
 // ---------------------------------------------------------------------------------
 constexpr int kPBlock = 256;
+#ifndef DSL_PAIR_NINE
+#define DSL_PAIR_NINE 1
+#endif
+constexpr bool kPairNine = DSL_PAIR_NINE != 0;  // nine-lane groups for the pair sweep's remainders (for_each_target)
 struct PairSlot {
   int srow, lx, g, own;  // staged row and tile-local x cell of the slot's cell; global slot and LDS record of its first target
   int rowbase, j;        // trow[ir].x and the first target's place inside its cell (query rows: k_pci_density_qpair)
@@ -1391,7 +1417,7 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
       continue;
     }
     const int nslots = m.pprefix[kTB * kTB];
-    for_each_target<SHARE, kPBlock>(nslots, tid, tid, [&](auto shared_c, int u, int sub, int k) {
+    for_each_target<SHARE, kPBlock, kPairNine>(nslots, tid, tid, [&](auto shared_c, int u, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;
       const PairSlot ps = pair_slot(m, u);
       const int srow = ps.srow, lx = ps.lx, g0 = ps.g;
@@ -1492,9 +1518,14 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
       }
       if constexpr (WIDE) return;  // (masks only: a tile that overflows the image has none, k_list_build marks its targets)
       if constexpr (SHARED) {
-        for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
-          acc[0] += __shfl_xor(acc[0], o, kWave);
-          acc[1] += __shfl_xor(acc[1], o, kWave);
+        if (k == 9) {  // (nine adjacent lanes, one run each: for_each_target<.., NINE>)
+          acc[0] = nine_lane_sum(acc[0]);
+          acc[1] = nine_lane_sum(acc[1]);
+        } else {
+          for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
+            acc[0] += __shfl_xor(acc[0], o, kWave);
+            acc[1] += __shfl_xor(acc[1], o, kWave);
+          }
         }
         if (sub != 0) return;
       }
@@ -1529,6 +1560,10 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
 //                  G-term; each sum is formed exactly as in its own pass (the two passes cost 0.245 + 0.204 ms at
 //                  4M particles, mostly per-tile and per-run work they share)
 constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2, kOutPci = 3;
+#ifndef DSL_FORCE_NINE
+#define DSL_FORCE_NINE 0
+#endif
+constexpr bool kForceNine = DSL_FORCE_NINE != 0;  // nine-lane groups for remainders of 33 .. 112 targets (for_each_target)
 
 // WANT_XS adds the build-defined XSPH and cohesion sums (BASELINE configs[4]) to the same sweep;
 // with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
@@ -1665,7 +1700,7 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int ntarg = m.tprefix[kTB * kTB];
     // short passes are shared out as in k_density_tiled: k lanes per target, each walking every
     // k-th run; after the butterfly the group's first lane finishes the target
-    for_each_target<SHARE>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
+    for_each_target<SHARE, kTBlock, kForceNine && !SLAB>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;
       const bool live = true;
       DSL_STAMP(t3);
@@ -2156,6 +2191,28 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             DSL_STAMP(t5);
             DSL_STAMP_ADD(3, t4, t5);
             if constexpr (SHARED)
+            if (k == 9) {  // (nine adjacent lanes, one run each: for_each_target<.., NINE>)
+              if constexpr (WANT_G) {
+                gx = nine_lane_sum(gx);
+                gy = nine_lane_sum(gy);
+                gz = nine_lane_sum(gz);
+              }
+              if constexpr (WANT_V) {
+                lx_ = nine_lane_sum(lx_);
+                ly_ = nine_lane_sum(ly_);
+                lz_ = nine_lane_sum(lz_);
+                lw_ = nine_lane_sum(lw_);
+              }
+              if constexpr (WANT_XS) {
+                cohx = nine_lane_sum(cohx);
+                cohy = nine_lane_sum(cohy);
+                cohz = nine_lane_sum(cohz);
+                xsx = nine_lane_sum(xsx);
+                xsy = nine_lane_sum(xsy);
+                xsz = nine_lane_sum(xsz);
+                xw_ = nine_lane_sum(xw_);
+              }
+            } else
             for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
               if constexpr (WANT_G) {
                 gx += __shfl_xor(gx, o, kWave);
