@@ -1560,10 +1560,6 @@ __global__ __launch_bounds__(kPBlock, 4) void k_density_pair(DevConsts c, TileGr
 //                  G-term; each sum is formed exactly as in its own pass (the two passes cost 0.245 + 0.204 ms at
 //                  4M particles, mostly per-tile and per-run work they share)
 constexpr int kOutIntegrate = 0, kOutAddForce = 1, kOutStore = 2, kOutPci = 3;
-#ifndef DSL_FORCE_NINE
-#define DSL_FORCE_NINE 0
-#endif
-constexpr bool kForceNine = DSL_FORCE_NINE != 0;  // nine-lane groups for remainders of 33 .. 112 targets (for_each_target)
 
 // WANT_XS adds the build-defined XSPH and cohesion sums (BASELINE configs[4]) to the same sweep;
 // with kOutAddForce the XSPH correction is stored through `vout` for the later Update.
@@ -1700,7 +1696,10 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
     const int ntarg = m.tprefix[kTB * kTB];
     // short passes are shared out as in k_density_tiled: k lanes per target, each walking every
     // k-th run; after the butterfly the group's first lane finishes the target
-    for_each_target<SHARE, kTBlock, kForceNine && !SLAB>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
+    // (nine-lane groups for remainders of 33 .. 112 targets, as in the pair sweep: measured 3 % SLOWER on the developed
+    // flow -- 6240-6255 against 6420-6475 in one call, profiles/r04_force_nine_lane_groups_ab.jsonl: seven more sums to
+    // combine over nine lanes in a kernel at its register limit -- and removed)
+    for_each_target<SHARE>(ntarg, tid, tperm, [&](auto shared_c, int t, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;
       const bool live = true;
       DSL_STAMP(t3);
@@ -2191,28 +2190,6 @@ __global__ __launch_bounds__(kTBlock, (WANT_G && WANT_V && !WANT_XS && !SLAB && 
             DSL_STAMP(t5);
             DSL_STAMP_ADD(3, t4, t5);
             if constexpr (SHARED)
-            if (k == 9) {  // (nine adjacent lanes, one run each: for_each_target<.., NINE>)
-              if constexpr (WANT_G) {
-                gx = nine_lane_sum(gx);
-                gy = nine_lane_sum(gy);
-                gz = nine_lane_sum(gz);
-              }
-              if constexpr (WANT_V) {
-                lx_ = nine_lane_sum(lx_);
-                ly_ = nine_lane_sum(ly_);
-                lz_ = nine_lane_sum(lz_);
-                lw_ = nine_lane_sum(lw_);
-              }
-              if constexpr (WANT_XS) {
-                cohx = nine_lane_sum(cohx);
-                cohy = nine_lane_sum(cohy);
-                cohz = nine_lane_sum(cohz);
-                xsx = nine_lane_sum(xsx);
-                xsy = nine_lane_sum(xsy);
-                xsz = nine_lane_sum(xsz);
-                xw_ = nine_lane_sum(xw_);
-              }
-            } else
             for (int o = 1; o < k; o <<= 1) {  // the lanes of a group are active together
               if constexpr (WANT_G) {
                 gx += __shfl_xor(gx, o, kWave);
