@@ -322,8 +322,12 @@ struct ScatterIds {
   int* dst;
 };
 __device__ __forceinline__ ScatterIds skin_ids(const ScatterArrays& a, const SkinGate& gate) {
-  if (gate.st != nullptr && gate.st->ids_sel == 0) return ScatterIds{a.ids_dst, const_cast<int*>(a.ids_src)};  // 1 -> 0
-  return ScatterIds{a.ids_src, a.ids_dst};
+  // (two selects on one flag, not "if (..) return {dst, src}; return {src, dst};": in the batched k_scatter hipcc 7.2
+  // hoisted that form's swap of the two pointers above its test of ids_sel and swapped them on BOTH paths -- s_mov pairs
+  // in front of the s_cmp in the ISA -- so that every second rebuild read the wrong map; tests/test_gpu_skin.py fails
+  // on it at once.  This form compiles to s_cselect_b32.)
+  const bool swap_ids = gate.st != nullptr && gate.st->ids_sel == 0;  // 1 -> 0
+  return ScatterIds{swap_ids ? a.ids_dst : a.ids_src, swap_ids ? const_cast<int*>(a.ids_src) : a.ids_dst};
 }
 // The scatter is a chain of dependent memory round trips -- position -> cell -> cell_start -> key row -> stores --
 // and with one particle per lane nothing but other waves covers them.  Everything that does not depend on the cell
@@ -374,12 +378,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(DevConsts c, ScatterArrays a
                                                     Soa3 ref = Soa3{nullptr, nullptr, nullptr}) {
   constexpr int U = kScatterUnroll;
   if (gate.closed()) return;
-  // (the two id maps by two selects on one flag -- NOT through skin_ids(): in this kernel hipcc 7.2 hoisted that
-  // function's swap of the two pointers above its test of ids_sel and swapped them on BOTH paths -- s_mov pairs in front
-  // of the s_cmp in the ISA -- so that every second rebuild read the wrong map; tests/test_gpu_skin.py fails on it at once)
-  const bool swap_ids = gate.st != nullptr && gate.st->ids_sel == 0;
-  const int* ids_src = swap_ids ? a.ids_dst : a.ids_src;
-  int* ids_dst = swap_ids ? const_cast<int*>(a.ids_src) : a.ids_dst;
+  const ScatterIds ids = skin_ids(a, gate);
+  const int* ids_src = ids.src;
+  int* ids_dst = ids.dst;
   const float tau = REF ? gate.st->tau : 0.0f;
   const int n = live_n(c);
   // the sort's positions (skin step: and velocities) are the first arrays of the payload in every caller: read once
