@@ -2840,6 +2840,8 @@ __global__ __launch_bounds__(kPBlock, 4) void k_pci_density_qpair(DevConsts c, T
       continue;
     }
     const int nslots = m.pprefix[kTB * kTB];
+    // (nine-lane groups for the remainders, as in k_density_pair: measured neutral here -- 4M PCISPH after 400 steps 1700-1707
+    // without, 1701-1704 with, profiles/r04_qpair_nine_lane_groups_ab.jsonl -- and not taken)
     for_each_target<true, kPBlock>(nslots, tid, tid, [&](auto shared_c, int u, int sub, int k) {
       constexpr bool SHARED = decltype(shared_c)::value;
       const PairSlot ps = pair_slot(m, u);
