@@ -217,37 +217,57 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ count,
                                                        const int* __restrict__ block_sums,
                                                        int* __restrict__ cell_start, DevStats* stats,
                                                        SkinGate gate = SkinGate{nullptr}) {
-  __shared__ int lds[kBlock / kWave];
+  __shared__ int carry_sums[kBlock / kWave];
+  __shared__ int wave_sums[4][kBlock / kWave];
   if (gate.closed()) return;
+  const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
   int4* src = reinterpret_cast<int4*>(count + (size_t)blockIdx.x * kScanTile);
   int4* dst = reinterpret_cast<int4*>(cell_start + (size_t)blockIdx.x * kScanTile);
+  // The tile's four counts per lane first, all four loads in flight and ahead of the carry's own round trip: behind a
+  // barrier the compiler may not move a load up, and a slab rank's grid is ONE round of 722 blocks whose time is one
+  // block's chain of round trips and barriers (18 us for 24 MB in the first form: load, scan with two barriers, store,
+  // four times over behind the carry's scan -- ten barriers; r04 slab rank profile).  ONE barrier now: the carry is a sum,
+  // not a scan, and the four sub-tiles' wave sums meet in LDS together with it.
+  int4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = src[k * kBlock + threadIdx.x];
   // the tile's offset: the sum of the tile sums in front of it (at most a few thousand ints, L2-resident: cheaper than
   // the one-block launch that used to turn them into a prefix)
-  int carry = 0;
-  {
-    int part = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += block_sums[i];
-    int total;
-    block_exclusive_scan(part, lds, total);
-    carry = total;
-  }
-  int mx = 0;
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) part += block_sums[i];
+  for (int off = kWave / 2; off > 0; off >>= 1) part += __shfl_xor(part, off, kWave);
+  if (lane == 0) carry_sums[wid] = part;
+  int mx = 0, s4[4], inc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int4 v = src[k * kBlock + threadIdx.x];
     // (most of the box is empty: only counts that are there are cleared)
-    if ((v.x | v.y | v.z | v.w) != 0) src[k * kBlock + threadIdx.x] = make_int4(0, 0, 0, 0);
-    mx = max(max(mx, max(v.x, v.y)), max(v.z, v.w));
-    const int s = (v.x + v.y) + (v.z + v.w);
-    int total;
-    const int ex = carry + block_exclusive_scan(s, lds, total);
+    if ((v[k].x | v[k].y | v[k].z | v[k].w) != 0) src[k * kBlock + threadIdx.x] = make_int4(0, 0, 0, 0);
+    mx = max(max(mx, max(v[k].x, v[k].y)), max(v[k].z, v[k].w));
+    s4[k] = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    inc[k] = wave_inclusive_scan(s4[k]);
+    if (lane == kWave - 1) wave_sums[k][wid] = inc[k];
+  }
+  __syncthreads();
+  int carry = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) carry += carry_sums[w];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+      const int t = wave_sums[k][w];
+      if (w < wid) off += t;
+      tot += t;
+    }
+    const int ex = carry + off + inc[k] - s4[k];
     int4 o;
     o.x = ex;
-    o.y = ex + v.x;
-    o.z = o.y + v.y;
-    o.w = o.z + v.z;
+    o.y = ex + v[k].x;
+    o.z = o.y + v[k].y;
+    o.w = o.z + v[k].z;
     dst[k * kBlock + threadIdx.x] = o;
-    carry += total;
+    carry += tot;
   }
   for (int off = kWave / 2; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off, kWave));
   // read first: almost every wave finds its maximum already recorded, and thousands of atomics on
